@@ -1,0 +1,391 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+CPU restatement (numpy, float64 by default) of the reference hot path:
+galacticglum/composer `composer/models/transformer.py` (Transformer teacher-forced
+training step + autoregressive decode).  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this module.  The shipped package
+`composer_amd` never imports it and fails loudly when its HIP library is missing.
+
+PARITY UNPINNED: the arithmetic of the reference path lives in TensorFlow
+(`tensorflow-gpu`, unpinned in `environment.yml:13`; TF 2.1/2.2 era), which is neither
+vendored under /root/reference nor installable offline, and the reference's own tests
+(`tests/test_sequences.py`) hold no golden vector for this path.  This oracle restates
+the reference's call sites op by op plus the published TF/Keras semantics of each op; it
+is cross-checked against an independent torch-autograd restatement in
+`tests/test_oracle.py` and frozen into `tests/golden/*.npz` by `tests/golden/make_golden.py`.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+"""
+import math
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Parameter surface (checkpoint names / shapes) -- transformer.py:114-116,189-190,663-694
+# --------------------------------------------------------------------------------------
+
+def param_specs(V, E, W, L):
+    """Ordered (name, shape, kind) list. kind in {'normal','ones','zeros'}.
+    Shapes: wte [V,E] (transformer.py:114), wpe [W,E] (:675-679), Conv1D weight
+    [in,out] and bias [1,out] (:189-190), LayerNormalization gamma/beta [E] (:551,563,694)."""
+    s = [("wte/weight", (V, E), "normal"), ("wpe/embeddings", (W, E), "normal")]
+    for i in range(L):
+        p = "decoder_blocks/%d/" % i
+        s += [
+            (p + "ln_1/gamma", (E,), "ones"), (p + "ln_1/beta", (E,), "zeros"),
+            (p + "attn/c_attn/weight", (E, 3 * E), "normal"), (p + "attn/c_attn/bias", (1, 3 * E), "zeros"),
+            (p + "attn/c_proj/weight", (E, E), "normal"), (p + "attn/c_proj/bias", (1, E), "zeros"),
+            (p + "ln_2/gamma", (E,), "ones"), (p + "ln_2/beta", (E,), "zeros"),
+            (p + "mlp/c_fc/weight", (E, 4 * E), "normal"), (p + "mlp/c_fc/bias", (1, 4 * E), "zeros"),
+            (p + "mlp/c_proj/weight", (4 * E, E), "normal"), (p + "mlp/c_proj/bias", (1, E), "zeros"),
+        ]
+    s += [("ln_f/gamma", (E,), "ones"), ("ln_f/beta", (E,), "zeros")]
+    return s
+
+
+def init_params(V, E, W, L, seed=0, mean=0.0, stddev=0.02, dtype=np.float64):
+    """TruncatedNormal(mean, stddev) resampled outside +-2 sigma (Keras initializer used at
+    transformer.py:115,188,670-673), gamma=1, beta=0, bias=0.  Uses numpy's own stream: TF's
+    Philox stream is not reproducible outside TF, parity runs load identical weights instead."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape, kind in param_specs(V, E, W, L):
+        if kind == "normal":
+            a = rng.standard_normal(shape)
+            bad = np.abs(a) > 2.0
+            while bad.any():
+                a[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(a) > 2.0
+            out[name] = (mean + stddev * a).astype(dtype)
+        elif kind == "ones":
+            out[name] = np.ones(shape, dtype)
+        else:
+            out[name] = np.zeros(shape, dtype)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Stateless dropout mask shared bit-for-bit with the HIP kernels (csrc/common.h: keep_mask).
+# The reference uses tf.nn.dropout (keep-scale 1/(1-p), transformer.py:271-272,361,444,496,506,
+# 681,794); TF's random stream is not reproducible, so both sides use this counter hash.
+# --------------------------------------------------------------------------------------
+
+def _mix32(x):
+    x = x.astype(np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_keep(seed, stream, idx, p):
+    """keep[idx] = hash(seed, stream, idx) >= p * 2^32  (uint32 compare).
+    stream identifies (step, layer, site); idx is the flat element index (uint64, folded)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    lo = idx & 0xFFFFFFFF
+    hi = idx >> 32
+    h = _mix32(lo ^ np.uint64(seed & 0xFFFFFFFF))
+    h = _mix32(h ^ ((hi * 0x9E3779B1) & 0xFFFFFFFF) ^ np.uint64(stream & 0xFFFFFFFF))
+    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
+    return h >= thr
+
+
+def dropout_stream(step, layer, site):
+    """site: 0 embed, 1 attention probabilities, 2 attn c_proj output, 3 mlp output."""
+    return ((step * 64 + layer) * 4 + site) & 0xFFFFFFFF
+
+
+# --------------------------------------------------------------------------------------
+# Primitive ops
+# --------------------------------------------------------------------------------------
+
+_GELU_C = math.sqrt(2.0 / math.pi)
+
+
+def gelu(x):
+    """transformer.py:35-40: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))."""
+    return 0.5 * x * (1.0 + np.tanh(_GELU_C * (x + 0.044715 * x ** 3)))
+
+
+def gelu_grad(x):
+    t = np.tanh(_GELU_C * (x + 0.044715 * x ** 3))
+    return 0.5 * (1.0 + t) + 0.5 * x * (1.0 - t * t) * _GELU_C * (1.0 + 3 * 0.044715 * x * x)
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    """Keras LayerNormalization non-fused path (transformer.py:551,563,694): biased variance over
+    the last axis, x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma."""
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mu) * rstd
+    return xhat * gamma + beta, (xhat, rstd)
+
+
+def layernorm_bwd(dy, cache, gamma):
+    xhat, rstd = cache
+    E = dy.shape[-1]
+    dgamma = (dy * xhat).reshape(-1, E).sum(0)
+    dbeta = dy.reshape(-1, E).sum(0)
+    g = dy * gamma
+    dx = rstd * (g - g.mean(-1, keepdims=True) - xhat * (g * xhat).mean(-1, keepdims=True))
+    return dx, dgamma, dbeta
+
+
+def causal_mask(nd, ns, dtype):
+    """transformer.py:290-301: m[i,j] = (i >= j - ns + nd)."""
+    i = np.arange(nd)[:, None]
+    j = np.arange(ns)
+    return (i >= j - ns + nd).astype(dtype)
+
+
+class Config:
+    def __init__(self, vocab_size, embedding_size, window_size, decoder_layers_count,
+                 attention_head_count, layer_normalization_epsilon=1e-5, scale=True,
+                 use_layer_normalization=True, attention_dropout_rate=0.0,
+                 residual_dropout_rate=0.0):
+        assert embedding_size % attention_head_count == 0  # transformer.py:255
+        self.V, self.E, self.W = vocab_size, embedding_size, window_size
+        self.L, self.H = decoder_layers_count, attention_head_count
+        self.D = embedding_size // attention_head_count
+        self.eps = layer_normalization_epsilon
+        self.scale = scale
+        self.use_ln = use_layer_normalization
+        self.p_attn = attention_dropout_rate
+        self.p_resid = residual_dropout_rate
+
+
+class OracleTransformer:
+    """Restatement of `Transformer` (transformer.py:599-960)."""
+
+    def __init__(self, cfg, params, dtype=np.float64, seed=0):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.p = {k: np.array(v, dtype=dtype) for k, v in params.items()}
+        self.m = {k: np.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: np.zeros_like(v) for k, v in self.p.items()}
+        self.iterations = 0          # Keras optimizer.iterations
+        self.seed = seed
+
+    # ---------------------------------------------------------------- forward
+    def _dropout(self, x, p, step, layer, site, training):
+        if not training or p <= 0.0:
+            return x, None
+        keep = dropout_keep(self.seed, dropout_stream(step, layer, site),
+                            np.arange(x.size, dtype=np.uint64), p).reshape(x.shape)
+        scale = 1.0 / (1.0 - p)
+        m = keep.astype(self.dtype) * scale
+        return x * m, m
+
+    def forward(self, x, past=None, training=False, step=0, keep_cache=False):
+        """Transformer.call (transformer.py:696-833).  x int [B,T].  past: list of L arrays
+        [2,B,H,Tp,D] or None.  Returns logits [B,T,V], presents (list of [2,B,H,Tk,D]), cache."""
+        c, P = self.cfg, self.p
+        x = np.asarray(x)
+        if past is not None:
+            x = x[:, -1:]                                            # :735-737
+        x = x.astype(np.int64)                                       # :758
+        B, T = x.shape
+        past_len = 0 if past is None else past[0].shape[-2]          # :760-765
+        pos = np.arange(past_len, T + past_len)                      # :770
+        if pos.max() >= c.W:
+            raise IndexError("position %d outside wpe table (%d rows)" % (pos.max(), c.W))
+        h = P["wte/weight"][x] + P["wpe/embeddings"][pos][None]      # :137-138,786,793
+        h, m_emb = self._dropout(h, c.p_resid, step, 0, 0, training)  # :794
+        cache = {"x": x, "pos": pos, "m_emb": m_emb, "layers": []}
+        presents = []
+        for i in range(c.L):
+            pre = "decoder_blocks/%d/" % i
+            lc = {}
+            x_in = h
+            # DecoderBlock.call :574-597 -- NOTE ln_1 output OVERWRITES the residual stream (:583-587)
+            if c.use_ln:
+                u, lc["ln1"] = layernorm_fwd(x_in, P[pre + "ln_1/gamma"], P[pre + "ln_1/beta"], c.eps)
+            else:
+                u = x_in
+            # Attention.call :397-448
+            qkv = u.reshape(-1, c.E) @ P[pre + "attn/c_attn/weight"] + P[pre + "attn/c_attn/bias"]  # :205-209
+            qkv = qkv.reshape(B, T, 3 * c.E)
+            q, k, v = np.split(qkv, 3, axis=2)                        # :417
+            sh = lambda t: t.reshape(B, T, c.H, c.D).transpose(0, 2, 1, 3)   # :385-395
+            q, k, v = sh(q), sh(k), sh(v)
+            if past is not None:                                      # :423-426
+                k = np.concatenate([past[i][0], k], axis=-2)
+                v = np.concatenate([past[i][1], v], axis=-2)
+            presents.append(np.stack([k, v], axis=0))                 # :435
+            w = q @ k.transpose(0, 1, 3, 2)                           # :339
+            if c.scale:
+                w = w * (1.0 / math.sqrt(c.D))                        # :345-348
+            nd, ns = w.shape[-2:]
+            b = causal_mask(nd, ns, self.dtype)[None, None]
+            w = w * b - 1e4 * (1 - b)                                 # :351-354
+            w = w - w.max(-1, keepdims=True)
+            pr = np.exp(w)
+            pr = pr / pr.sum(-1, keepdims=True)                       # :360
+            prd, m_att = self._dropout(pr, c.p_attn, step, i, 1, training)   # :361
+            a = prd @ v                                               # :367
+            a = a.transpose(0, 2, 1, 3).reshape(B, T, c.E)            # :373-383
+            ao = a.reshape(-1, c.E) @ P[pre + "attn/c_proj/weight"] + P[pre + "attn/c_proj/bias"]  # :443
+            ao = ao.reshape(B, T, c.E)
+            ao, m_ao = self._dropout(ao, c.p_resid, step, i, 2, training)    # :444
+            r = u + ao                                                # :587
+            if c.use_ln:
+                n, lc["ln2"] = layernorm_fwd(r, P[pre + "ln_2/gamma"], P[pre + "ln_2/beta"], c.eps)  # :591
+            else:
+                n = r
+            fc = n.reshape(-1, c.E) @ P[pre + "mlp/c_fc/weight"] + P[pre + "mlp/c_fc/bias"]      # :504
+            g = gelu(fc)
+            mo = g @ P[pre + "mlp/c_proj/weight"] + P[pre + "mlp/c_proj/bias"]                     # :505
+            mo = mo.reshape(B, T, c.E)
+            mo, m_mo = self._dropout(mo, c.p_resid, step, i, 3, training)    # :506
+            h = r + mo                                                # :594
+            if keep_cache:
+                lc.update(u=u, q=q, k=k, v=v, pr=pr, m_att=m_att, prd=prd, a=a, m_ao=m_ao, r=r, n=n,
+                          fc=fc, g=g, m_mo=m_mo)
+                cache["layers"].append(lc)
+        hf, lnf = layernorm_fwd(h, P["ln_f/gamma"], P["ln_f/beta"], c.eps)   # :811 (always applied)
+        logits = hf @ P["wte/weight"].T                               # :139-144,818
+        cache["hf"], cache["lnf"] = hf, lnf
+        return logits, presents, cache
+
+    # ---------------------------------------------------------------- loss
+    @staticmethod
+    def loss_acc(logits, y):
+        """SparseCategoricalCrossentropy(from_logits=True), SUM_OVER_BATCH_SIZE (transformer.py:888,918)
+        and batch accuracy (:924-926, argmax lowest index on ties)."""
+        V = logits.shape[-1]
+        z = logits.reshape(-1, V)
+        y = np.asarray(y).reshape(-1).astype(np.int64)
+        zmax = z.max(-1, keepdims=True)
+        lse = zmax[:, 0] + np.log(np.exp(z - zmax).sum(-1))
+        nll = lse - z[np.arange(z.shape[0]), y]
+        acc = (z.argmax(-1) == y).mean()
+        return nll.mean(), acc
+
+    def loss_and_grads(self, x, y, training=True, step=0):
+        """GradientTape over Transformer.call + loss (transformer.py:916-920), written out by hand
+        (SURVEY appendix A)."""
+        c, P = self.cfg, self.p
+        logits, _, cache = self.forward(x, training=training, step=step, keep_cache=True)
+        B, T = cache["x"].shape
+        N = B * T
+        loss, acc = self.loss_acc(logits, y)
+        z = logits.reshape(N, c.V)
+        yy = np.asarray(y).reshape(-1).astype(np.int64)
+        sm = np.exp(z - z.max(-1, keepdims=True))
+        sm /= sm.sum(-1, keepdims=True)
+        dz = sm
+        dz[np.arange(N), yy] -= 1.0
+        dz /= N
+        G = {k: np.zeros_like(v) for k, v in P.items()}
+        hf = cache["hf"].reshape(N, c.E)
+        G["wte/weight"] += dz.T @ hf                                  # tied logits wgrad
+        dhf = (dz @ P["wte/weight"]).reshape(B, T, c.E)
+        dh, G["ln_f/gamma"], G["ln_f/beta"] = layernorm_bwd(dhf, cache["lnf"], P["ln_f/gamma"])
+        sc = (1.0 / math.sqrt(c.D)) if c.scale else 1.0
+        for i in reversed(range(c.L)):
+            pre = "decoder_blocks/%d/" % i
+            lc = cache["layers"][i]
+            dx_out = dh
+            dmo = dx_out if lc["m_mo"] is None else dx_out * lc["m_mo"]
+            dmo2 = dmo.reshape(N, c.E)
+            G[pre + "mlp/c_proj/weight"] = lc["g"].T @ dmo2
+            G[pre + "mlp/c_proj/bias"] = dmo2.sum(0, keepdims=True)
+            dg = dmo2 @ P[pre + "mlp/c_proj/weight"].T
+            dfc = dg * gelu_grad(lc["fc"])
+            G[pre + "mlp/c_fc/weight"] = lc["n"].reshape(N, c.E).T @ dfc
+            G[pre + "mlp/c_fc/bias"] = dfc.sum(0, keepdims=True)
+            dn = (dfc @ P[pre + "mlp/c_fc/weight"].T).reshape(B, T, c.E)
+            if c.use_ln:
+                dln, G[pre + "ln_2/gamma"], G[pre + "ln_2/beta"] = layernorm_bwd(dn, lc["ln2"], P[pre + "ln_2/gamma"])
+            else:
+                dln = dn
+            dr = dx_out + dln
+            dao = dr if lc["m_ao"] is None else dr * lc["m_ao"]
+            dao2 = dao.reshape(N, c.E)
+            G[pre + "attn/c_proj/weight"] = lc["a"].reshape(N, c.E).T @ dao2
+            G[pre + "attn/c_proj/bias"] = dao2.sum(0, keepdims=True)
+            da = (dao2 @ P[pre + "attn/c_proj/weight"].T).reshape(B, T, c.H, c.D).transpose(0, 2, 1, 3)
+            dv = lc["prd"].transpose(0, 1, 3, 2) @ da
+            dprd = da @ lc["v"].transpose(0, 1, 3, 2)
+            dpr = dprd if lc["m_att"] is None else dprd * lc["m_att"]
+            pr = lc["pr"]
+            dw = pr * (dpr - (dpr * pr).sum(-1, keepdims=True))
+            dw = dw * causal_mask(T, T, self.dtype)[None, None]       # d(w*b)
+            dq = sc * (dw @ lc["k"])
+            dk = sc * (dw.transpose(0, 1, 3, 2) @ lc["q"])
+            mh = lambda t: t.transpose(0, 2, 1, 3).reshape(B, T, c.E)
+            dqkv = np.concatenate([mh(dq), mh(dk), mh(dv)], axis=2).reshape(N, 3 * c.E)
+            G[pre + "attn/c_attn/weight"] = lc["u"].reshape(N, c.E).T @ dqkv
+            G[pre + "attn/c_attn/bias"] = dqkv.sum(0, keepdims=True)
+            du = dr + (dqkv @ P[pre + "attn/c_attn/weight"].T).reshape(B, T, c.E)
+            if c.use_ln:
+                dh, G[pre + "ln_1/gamma"], G[pre + "ln_1/beta"] = layernorm_bwd(du, lc["ln1"], P[pre + "ln_1/gamma"])
+            else:
+                dh = du
+        dh0 = dh if cache["m_emb"] is None else dh * cache["m_emb"]
+        np.add.at(G["wte/weight"], cache["x"].reshape(-1), dh0.reshape(N, c.E))   # gather grad
+        G["wpe/embeddings"][cache["pos"]] += dh0.sum(0)
+        return loss, acc, G, logits
+
+    # ---------------------------------------------------------------- optimizer
+    def adam_step(self, G, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        """Keras OptimizerV2 Adam dense update (transformer.py:887,921): eps OUTSIDE the bias
+        correction: theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps).  wpe's sparse path is the
+        non-lazy Keras sparse Adam == dense update with zero rows."""
+        self.iterations += 1
+        t = self.iterations
+        alpha = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        for k in self.p:
+            g = G[k]
+            self.m[k] = beta1 * self.m[k] + (1 - beta1) * g
+            self.v[k] = beta2 * self.v[k] + (1 - beta2) * g * g
+            self.p[k] = self.p[k] - alpha * self.m[k] / (np.sqrt(self.v[k]) + eps)
+
+    def train_step(self, x, y, lr, training=True):
+        """One iteration of the loop body at transformer.py:914-930."""
+        loss, acc, G, _ = self.loss_and_grads(x, y, training=training, step=self.iterations)
+        self.adam_step(G, lr)
+        return loss, acc
+
+    # ---------------------------------------------------------------- decode
+    def generate_literal(self, prompt, n, temperature=0.0, rng=None):
+        """Bit-for-bit restatement of cli.py:659-676: `past` is never fed back, so after the first
+        step the model sees ONE token at position 0.  temperature 0 => argmax (lowest index)."""
+        x = np.asarray(prompt, dtype=np.int64)[None]
+        out = []
+        for _ in range(n):
+            logits, _, _ = self.forward(x)
+            out.append(self._sample(logits[0, -1], temperature, rng))
+            x = np.array([[out[-1]]])
+        return out
+
+    def generate_kv(self, prompt, n, temperature=0.0, rng=None):
+        """model(x, past=presents) semantics (transformer.py:735-765,423-426): prompt once, then one
+        new token per step at position P+i attending to the whole cache."""
+        x = np.asarray(prompt, dtype=np.int64)[None]
+        if x.shape[1] + n - 1 > self.cfg.W:
+            raise IndexError("prompt_len + length - 1 exceeds window_size")
+        logits, past, _ = self.forward(x)
+        out = []
+        for i in range(n):
+            out.append(self._sample(logits[0, -1], temperature, rng))
+            if i + 1 < n:
+                logits, past, _ = self.forward(np.array([[out[-1]]]), past=past)
+        return out
+
+    @staticmethod
+    def _sample(z, temperature, rng):
+        if temperature <= 0.0:
+            return int(np.argmax(z))
+        z = z / temperature                                           # cli.py:671
+        p = np.exp(z - z.max()); p /= p.sum()
+        return int(rng.choice(len(p), p=p))                           # tf.random.categorical, cli.py:673
+
+
+def synthetic_batch(rng, V, B, T):
+    """x, y = seq[:, :-1], seq[:, 1:] -- the shift-by-one of models/__init__.py:304."""
+    seq = rng.integers(0, V, size=(B, T + 1), dtype=np.int32)
+    return seq[:, :-1].copy(), seq[:, 1:].copy()

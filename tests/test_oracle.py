@@ -1,0 +1,155 @@
+"""CPU tests that pin the numpy oracle: (1) against an INDEPENDENT torch-autograd restatement of
+transformer.py:696-833 (float64, must agree to ~1e-10), (2) against the committed golden vectors."""
+import math
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle import transformer_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def torch_forward(P, x, cfg, past_len=0):
+    """Independent restatement with torch ops + autograd (no shared code with the oracle)."""
+    B, T = x.shape
+    E, H, D = cfg.E, cfg.H, cfg.D
+    pos = torch.arange(past_len, past_len + T)
+    h = P["wte/weight"][x] + P["wpe/embeddings"][pos]
+    for i in range(cfg.L):
+        p = "decoder_blocks/%d/" % i
+        if cfg.use_ln:
+            h = torch.nn.functional.layer_norm(h, (E,), P[p + "ln_1/gamma"], P[p + "ln_1/beta"], cfg.eps)
+        qkv = h.reshape(-1, E) @ P[p + "attn/c_attn/weight"] + P[p + "attn/c_attn/bias"]
+        q, k, v = qkv.reshape(B, T, 3 * E).split(E, dim=2)
+        q, k, v = [t.reshape(B, T, H, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+        w = q @ k.transpose(-1, -2)
+        if cfg.scale:
+            w = w * (1.0 / math.sqrt(D))
+        b = torch.tril(torch.ones(T, T, dtype=w.dtype))
+        w = w * b - 1e4 * (1 - b)
+        w = torch.softmax(w, -1)
+        a = (w @ v).permute(0, 2, 1, 3).reshape(B, T, E)
+        a = (a.reshape(-1, E) @ P[p + "attn/c_proj/weight"] + P[p + "attn/c_proj/bias"]).reshape(B, T, E)
+        h = h + a
+        m = h
+        if cfg.use_ln:
+            m = torch.nn.functional.layer_norm(h, (E,), P[p + "ln_2/gamma"], P[p + "ln_2/beta"], cfg.eps)
+        f = m.reshape(-1, E) @ P[p + "mlp/c_fc/weight"] + P[p + "mlp/c_fc/bias"]
+        f = 0.5 * f * (1 + torch.tanh(math.sqrt(2 / math.pi) * (f + 0.044715 * f ** 3)))
+        f = (f @ P[p + "mlp/c_proj/weight"] + P[p + "mlp/c_proj/bias"]).reshape(B, T, E)
+        h = h + f
+    h = torch.nn.functional.layer_norm(h, (E,), P["ln_f/gamma"], P["ln_f/beta"], cfg.eps)
+    return h @ P["wte/weight"].T
+
+
+@pytest.mark.parametrize("E,H,L,T,use_ln", [(32, 4, 2, 16, True), (64, 4, 2, 33, True), (32, 2, 1, 8, False)])
+def test_oracle_matches_torch_autograd(E, H, L, T, use_ln):
+    V, W, B = 390, 40, 2
+    cfg = O.Config(V, E, W, L, H, use_layer_normalization=use_ln)
+    params = O.init_params(V, E, W, L, seed=3)
+    rng = np.random.default_rng(5)
+    # non-trivial gamma/beta/bias so their gradients are exercised
+    for k in params:
+        if k.endswith(("gamma", "beta", "bias")):
+            params[k] = params[k] + 0.1 * rng.standard_normal(params[k].shape)
+    x, y = O.synthetic_batch(rng, V, B, T)
+    orc = O.OracleTransformer(cfg, params)
+    loss, acc, G, logits = orc.loss_and_grads(x, y, training=False)
+
+    P = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    tl = torch_forward(P, torch.tensor(x, dtype=torch.long), cfg)
+    tloss = torch.nn.functional.cross_entropy(tl.reshape(-1, V), torch.tensor(y, dtype=torch.long).reshape(-1))
+    tloss.backward()
+    assert np.allclose(logits, tl.detach().numpy(), atol=1e-11, rtol=0)
+    assert abs(loss - tloss.item()) < 1e-12
+    for k in params:
+        if not use_ln and ("ln_1" in k or "ln_2" in k):
+            continue
+        g = P[k].grad.numpy()
+        assert np.allclose(G[k], g, atol=1e-12, rtol=1e-9), k
+
+
+def test_adam_is_keras_formulation():
+    """theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+1e-7): differs from torch.optim.Adam's eps placement."""
+    cfg = O.Config(390, 32, 16, 1, 4)
+    params = O.init_params(390, 32, 16, 1, seed=0)
+    orc = O.OracleTransformer(cfg, params)
+    G = {k: np.full_like(v, 0.5) for k, v in params.items()}
+    p0 = {k: v.copy() for k, v in orc.p.items()}
+    orc.adam_step(G, 1e-3)
+    m, v = 0.05, 0.00025
+    alpha = 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    exp = alpha * m / (math.sqrt(v) + 1e-7)
+    for k in params:
+        assert np.allclose(p0[k] - orc.p[k], exp, rtol=1e-12)
+    assert orc.iterations == 1
+
+
+def test_kv_cache_equals_full_forward():
+    """model(x, past=presents) (transformer.py:735-765) must equal the last row of the full forward."""
+    cfg = O.Config(390, 32, 24, 2, 4)
+    orc = O.OracleTransformer(cfg, O.init_params(390, 32, 24, 2, seed=1))
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, 390, size=(1, 12))
+    full, _, _ = orc.forward(ids)
+    lg, past, _ = orc.forward(ids[:, :7])
+    for t in range(7, 12):
+        lg, past, _ = orc.forward(ids[:, t:t + 1], past=past)
+        assert np.allclose(lg[0, -1], full[0, t], atol=1e-12)
+
+
+def test_masked_scores_are_exactly_zero_probability():
+    """-1e4 masking (transformer.py:354) underflows to exactly 0 => skipping masked tiles is exact."""
+    cfg = O.Config(390, 32, 16, 1, 4)
+    orc = O.OracleTransformer(cfg, O.init_params(390, 32, 16, 1, seed=2))
+    x = np.random.default_rng(1).integers(0, 390, size=(1, 16))
+    _, _, cache = orc.forward(x, keep_cache=True)
+    pr = cache["layers"][0]["pr"]
+    assert (np.triu(pr[0, 0], 1) == 0).all()
+
+
+def test_dropout_keep_rate_and_determinism():
+    k = O.dropout_keep(123, O.dropout_stream(1, 2, 3), np.arange(1 << 16, dtype=np.uint64), 0.1)
+    assert abs(k.mean() - 0.9) < 0.01
+    k2 = O.dropout_keep(123, O.dropout_stream(1, 2, 3), np.arange(1 << 16, dtype=np.uint64), 0.1)
+    assert (k == k2).all()
+
+
+def test_param_count_matches_survey():
+    """C2 = 19 639 296, C4 = 86 928 384, C1(W=1024) = 6 680 576."""
+    n = lambda V, E, W, L: sum(int(np.prod(s)) for _, s, _ in O.param_specs(V, E, W, L))
+    assert n(390, 512, 1024, 6) == 19639296
+    assert n(390, 768, 2048, 12) == 86928384
+    assert n(390, 256, 1024, 8) == 6680576
+
+
+def load_golden(name):
+    g = np.load(os.path.join(HERE, "golden", "transformer_%s.npz" % name))
+    V, E, H, L, W, T, B = [int(v) for v in g["cfg"]]
+    params = {k[6:]: g[k].astype(np.float64) for k in g.files if k.startswith("param:")}
+    return g, O.Config(V, E, W, L, H), params
+
+
+def decode_params(g, cfg, params):
+    kinds = {n: k for n, _, k in O.param_specs(cfg.V, cfg.E, cfg.W, cfg.L)}
+    return {k: ((v.astype(np.float32) * g["decode_scale"]) if kinds[k] == "normal"
+                else v.astype(np.float32)).astype(np.float64) for k, v in params.items()}
+
+
+@pytest.mark.parametrize("name", ["gA", "gB", "gC"])
+def test_oracle_reproduces_golden(name):
+    g, cfg, params = load_golden(name)
+    orc = O.OracleTransformer(cfg, params)
+    loss, acc, G, logits = orc.loss_and_grads(g["x"][0], g["y"][0], training=False)
+    assert np.allclose(logits, g["logits0"], atol=1e-6)
+    for k in params:
+        assert abs(np.sqrt((G[k] ** 2).sum()) - g["gradnorm:" + k]) < 1e-12
+    for s in range(len(g["losses"])):
+        l, a = orc.train_step(g["x"][s], g["y"][s], float(g["lr"]), training=False)
+        assert abs(l - g["losses"][s]) < 1e-12 and abs(a - g["accs"][s]) < 1e-12
+    orc0 = O.OracleTransformer(cfg, decode_params(g, cfg, params))
+    n = len(g["greedy_kv"])
+    assert orc0.generate_kv(g["prompt"], n) == g["greedy_kv"].tolist()
+    assert orc0.generate_literal(g["prompt"], n) == g["greedy_literal"].tolist()
