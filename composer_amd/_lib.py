@@ -1,0 +1,110 @@
+"""ctypes binding of libcomposer_hip.so (C ABI declared in include/composer_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or no MI355X is visible when a device
+context is requested, this module raises.  (The numpy oracle under oracle/ is test infrastructure and is
+never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcomposer_hip.so")
+
+CMP_FP32, CMP_BF16 = 0, 1
+DECODE_LITERAL, DECODE_KV = 0, 1
+KIND_VALUE, KIND_ADAM_M, KIND_ADAM_V, KIND_GRAD = 0, 1, 2, 3
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("embedding_size", C.c_int32), ("window_size", C.c_int32),
+        ("layers", C.c_int32), ("heads", C.c_int32), ("ln_eps", C.c_float),
+        ("scale_attention", C.c_int32), ("use_layer_norm", C.c_int32),
+        ("attn_dropout", C.c_float), ("resid_dropout", C.c_float),
+        ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_seq", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+_P = C.c_void_p
+_i, _f, _i64, _u64, _u32 = C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_uint32
+
+# name -> (restype, argtypes); every symbol declared in include/composer_hip.h
+SIGNATURES = {
+    "cmp_last_error": (C.c_char_p, []),
+    "cmp_version": (_i, []),
+    "cmp_device_count": (_i, []),
+    "cmp_ctx_create": (_i, [_i, C.POINTER(_P)]),
+    "cmp_ctx_destroy": (_i, [_P]),
+    "cmp_sync": (_i, [_P]),
+    "cmp_ctx_stream": (_P, [_P]),
+    "cmp_dp_unique_id": (_i, [_P]),
+    "cmp_dp_init": (_i, [_P, _i, _i, _P]),
+    "cmp_dp_allreduce_test": (_i, [_P, _P, _i]),
+    "cmp_model_create": (_i, [_P, C.POINTER(ModelCfg), C.POINTER(_P)]),
+    "cmp_model_destroy": (_i, [_P]),
+    "cmp_param_count": (_i, [_P, C.POINTER(_i)]),
+    "cmp_param_info": (_i, [_P, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i64 * 4), C.POINTER(_i64)]),
+    "cmp_param_get": (_i, [_P, C.c_char_p, _i, _P, _i64]),
+    "cmp_param_set": (_i, [_P, C.c_char_p, _i, _P, _i64]),
+    "cmp_adam_iter_get": (_i, [_P, C.POINTER(_i64)]),
+    "cmp_adam_iter_set": (_i, [_P, _i64]),
+    "cmp_train_step": (_i, [_P, _P, _P, _i, _i, _f, C.POINTER(_f), C.POINTER(_f)]),
+    "cmp_train_step_dev": (_i, [_P, _P, _P, _i, _i, _f]),
+    "cmp_train_metrics": (_i, [_P, C.POINTER(_f), C.POINTER(_f)]),
+    "cmp_loss_and_grads": (_i, [_P, _P, _P, _i, _i, C.POINTER(_f), C.POINTER(_f)]),
+    "cmp_eval_step": (_i, [_P, _P, _P, _i, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
+    "cmp_forward_logits": (_i, [_P, _P, _i, _i, _P]),
+    "cmp_decode_begin": (_i, [_P, _P, _i, _i, _f, _u64]),
+    "cmp_decode_steps": (_i, [_P, _i, _P]),
+    "cmp_k_embed_fwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_k_embed_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_k_layernorm_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _f, _i]),
+    "cmp_k_layernorm_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i]),
+    "cmp_k_layernorm_bwd_ws": (_i64, [_i, _i]),
+    "cmp_k_gemm": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_k_colsum": (_i, [_P, _P, _i, _P, _i, _i, _i]),
+    "cmp_k_attn_fwd": (_i, [_P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_k_attn_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_k_softmax_xent": (_i, [_P, _P, _i, _P, _P, _P, _P, _i, _i, _f, _i]),
+    "cmp_k_adam": (_i, [_P, _P, _P, _P, _P, _P, _i64, _f, _f, _f, _f, _i64, _f]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (no GPU needed for this) and sets every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "libcomposer_hip.so not found at %s -- build it with `python -m composer_amd.build` "
+            "(hipcc, gfx950).  composer_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().cmp_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HipLibraryError("%s failed (status %d): %s" % (what or "libcomposer_hip call", rc, last_error()))
+
+
+def require_gpu():
+    n = load().cmp_device_count()
+    if n <= 0:
+        raise HipLibraryError("no HIP device visible: composer_amd needs an MI355X (gfx950); there is no CPU fallback")
+    return n

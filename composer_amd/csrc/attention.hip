@@ -1,0 +1,490 @@
+// attention.hip -- causal scaled-dot-product attention of Attention._multihead_attention
+// (transformer.py:331-371) and its gradient, flash-style: the [B,H,T,T] score tensor the reference
+// materialises ~6 times per layer is never written to HBM.
+//
+// Semantics kept from the reference: w = (q.k^T) * rsqrt(D) (:339-348); masked scores are EXACTLY -1e4
+// (:351-354), which underflows to probability 0 in fp32, so key tiles entirely above the diagonal are
+// skipped without changing a bit; softmax (:360); dropout on the probabilities (:361); w.v (:367).
+// split_heads/merge_heads (:373-395) are pure addressing here: q,k,v are read straight out of the
+// head-merged c_attn output [B,T,3E] and o is written head-merged [B,T,E].
+//
+// Matrix-core mapping (32x32 MFMA; bf16: 32x32x16, fp32 parity mode: 32x32x2 = exact fma chains):
+//   forward / dQ : S^T = K.Q^T with the QUERY on the lane  -> row max/sum are lane-local (+1 cross-half
+//                  exchange), and the f32 accumulator tile is directly the B operand of O^T += V^T.P^T
+//                  (resp. dQ^T += K^T.dS^T) -- no LDS round trip for P.
+//   dK/dV        : S = Q.K^T with the KEY on the lane -> P and dS are directly the B operands of
+//                  dV^T += dO^T.P and dK^T += Q^T.dS; each wave keeps dK^T/dV^T of its 32 keys in registers.
+//   "transposed" A operands (V^T, K^T, Q^T, dO^T) come from row-major LDS images through
+//   ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (fp32).
+#include "common.h"
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+
+template <typename T> struct AT;
+template <> struct AT<bf16_t> {
+    static constexpr int KSTEP = 16;
+    static constexpr int VN = 8;
+    typedef bf16x8 frag;
+    static constexpr bool EXACT = false;
+};
+template <> struct AT<float> {
+    static constexpr int KSTEP = 2;
+    static constexpr int VN = 4;
+    typedef float frag;
+    static constexpr bool EXACT = true;
+};
+
+template <typename T> using frag_t = typename AT<T>::frag;
+
+template <typename T, int D> struct Geo {
+    static constexpr int DP = D < 32 ? 32 : D;                       // padded head width (zero filled)
+    static constexpr int DT = DP / 32;                               // 32-row output tiles along d
+    // LDS row stride in elements. bf16: 2*S bytes, multiple of 16, odd number of 16-B chunks (b128 row reads
+    // conflict-free).  fp32: odd (b32 row reads with the row on the lane conflict-free).
+    static constexpr int S = std::is_same<T, float>::value ? DP + 1 : DP + 8;
+    static constexpr int NS = D / AT<T>::KSTEP;                      // MFMA steps over the head dimension
+};
+
+template <typename T> __device__ __forceinline__ f32x16 mfma32(frag_t<T> a, frag_t<T> b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma32<bf16_t>(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma32<float>(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// stage `nrows` rows x D of a head-merged global tensor into an LDS image [nrows][S], zero filled
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(T* img, const T* __restrict__ g, int64_t gstride, int row0, int row_end,
+                                           int nrows, int tid) {
+    constexpr int VN = AT<T>::VN, DP = Geo<T, D>::DP, S = Geo<T, D>::S;
+    constexpr int CPR = DP / VN;
+    for (int c = tid; c < nrows * CPR; c += 256) {
+        int r = c / CPR, cc = c % CPR;
+        Vec16<T> v;
+#pragma unroll
+        for (int j = 0; j < VN; j++) v.set(j, 0.f);
+        if (row0 + r < row_end && cc * VN < D) v = ld16(g + (int64_t)(row0 + r) * gstride + cc * VN);
+        if (std::is_same<T, float>::value) {
+#pragma unroll
+            for (int j = 0; j < VN; j++) img[r * S + cc * VN + j] = from_f32<T>(v.get(j));
+        } else {
+            st16(img + r * S + cc * VN, v);
+        }
+    }
+}
+
+// per-lane register fragments of a [32 rows][D] global tile used as the MFMA B operand B[k=d][col=row]
+template <typename T, int D>
+__device__ __forceinline__ void load_bfrags(frag_t<T>* f, const T* __restrict__ g,
+                                            int64_t gstride, int row, bool valid, int h) {
+    constexpr int NS = Geo<T, D>::NS;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        if constexpr (std::is_same<T, float>::value) {
+            f[s] = valid ? g[(int64_t)row * gstride + 2 * s + h] : 0.f;
+        } else {
+            bf16x8 z;
+#pragma unroll
+            for (int j = 0; j < 8; j++) z[j] = (bf16_t)0.f;
+            f[s] = valid ? *reinterpret_cast<const bf16x8*>(g + (int64_t)row * gstride + 16 * s + 8 * h) : z;
+        }
+    }
+}
+
+// C(32x32) += rows(img[row0..row0+31][0..D)) . Bfrag      (A operand read row-wise from the LDS image)
+template <typename T, int D>
+__device__ __forceinline__ f32x16 mma_rows(const T* img, int row0, const frag_t<T>* bf,
+                                           int lane, f32x16 acc) {
+    constexpr int NS = Geo<T, D>::NS, S = Geo<T, D>::S;
+    const int r = row0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        frag_t<T> a;
+        if constexpr (std::is_same<T, float>::value) a = img[r * S + 2 * s + h];
+        else a = *reinterpret_cast<const bf16x8*>(img + r * S + 16 * s + 8 * h);
+        acc = mfma32<T>(a, bf[s], acc);
+    }
+    return acc;
+}
+
+// Y^T tile dt (32 d-rows x 32 cols) += img[krow0..krow0+31][32dt..32dt+31]^T . X, X = a 32x32 accumulator
+// (rows = the contraction index, in registers; cols on the lanes) used directly as the B operand.
+template <typename T, int D>
+__device__ __forceinline__ f32x16 mma_acc_b(const T* img, int krow0, int dt, const f32x16& x, int lane, f32x16 acc) {
+    constexpr int S = Geo<T, D>::S;
+    const int h = lane >> 5;
+    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float a = img[(krow0 + rho(r, h)) * S + 32 * dt + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[r], acc, 0, 0, 0);
+        }
+    } else {
+        const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int col = 32 * dt + 16 * (G & 1) + 4 * p;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int kr = krow0 + 16 * s + 4 * (G >> 1) + q;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + kr * S + col));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + (kr + 8) * S + col));
+            bf16x8 a, b;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                a[j] = lo[j];
+                a[4 + j] = hi[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) b[j] = (bf16_t)x[8 * s + j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+template <bool EXACT> __device__ __forceinline__ float exp_f(float x) { return EXACT ? expf(x) : __expf(x); }
+
+// store a transposed accumulator tile Y^T[d][row] (d in registers, row on the lane) to out[row][d0 + d]
+template <typename T, int D>
+__device__ __forceinline__ void store_t_tile(T* __restrict__ out, int64_t ostride, int row, bool valid, int dt,
+                                             const f32x16& y, float mul, int h) {
+    if (!valid) return;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        int d = 32 * dt + 8 * g + 4 * h;
+        if (d < D) {
+            if constexpr (std::is_same<T, float>::value) {
+                f32x4 v = {y[4 * g] * mul, y[4 * g + 1] * mul, y[4 * g + 2] * mul, y[4 * g + 3] * mul};
+                *reinterpret_cast<f32x4*>(out + (int64_t)row * ostride + d) = v;
+            } else {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = (bf16_t)(y[4 * g + j] * mul);
+                *reinterpret_cast<bf16x4*>(out + (int64_t)row * ostride + d) = v;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// forward.  grid (ceil(T/128), B*H), 256 threads: wave w owns query rows [qb*128 + 32w, +32)
+// =================================================================================================
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                       float* __restrict__ lse, int Tn, int H, float scale,
+                                                       DropCfg drop) {
+    using G = Geo<T, D>;
+    constexpr bool EXACT = AT<T>::EXACT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);          // [64][S]
+    T* Vs = Ks + 64 * G::S;                          // [64][S]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int b = blockIdx.y / H, hd = blockIdx.y % H;
+    const int E = H * D;
+    const int64_t rs = 3 * E;                        // row stride of qkv
+    const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
+    const T* kg = qg + E;
+    const T* vg = qg + 2 * E;
+    const int q0w = blockIdx.x * 128 + wave * 32;
+    const int q = q0w + (lane & 31);
+    const bool qvalid = q < Tn;
+    frag_t<T> qf[G::NS];
+    load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
+
+    f32x16 oacc[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    const int kv_end = min(Tn, blockIdx.x * 128 + 128);
+    const uint64_t drop_row = ((uint64_t)blockIdx.y * Tn + q) * (uint64_t)Tn;
+
+    for (int kt0 = 0; kt0 < kv_end; kt0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(Ks, kg, rs, kt0, Tn, 64, tid);
+        stage_rows<T, D>(Vs, vg, rs, kt0, Tn, 64, tid);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            const int k0 = kt0 + 32 * sub;
+            if (k0 > q0w + 31 || k0 >= Tn) continue;          // wave-uniform: tile entirely masked
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[r] = 0.f;
+            s = mma_rows<T, D>(Ks, 32 * sub, qf, lane, s);
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int key = k0 + rho(r, h);
+                float v = s[r] * scale;
+                if (key > q || key >= Tn) v = -1e4f;          // w*b - 1e4*(1-b), transformer.py:354
+                s[r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+            mloc = fmaxf(mloc, xhalf(mloc));
+            const float mnew = fmaxf(m, mloc);
+            const float alpha = exp_f<EXACT>(m - mnew);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float p = exp_f<EXACT>(s[r] - mnew);
+                ps += p;
+                if (drop.thr) p = apply_drop(drop, drop_row + (uint64_t)(k0 + rho(r, h)), p);
+                s[r] = p;
+            }
+            lsum = lsum * alpha + ps;
+            m = mnew;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; dt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+                oacc[dt] = mma_acc_b<T, D>(Vs, 32 * sub, dt, s, lane, oacc[dt]);
+            }
+        }
+    }
+    const float ltot = lsum + xhalf(lsum);
+    const float inv = 1.0f / ltot;
+    T* og = o + (int64_t)b * Tn * E + hd * D;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(og, E, q, qvalid, dt, oacc[dt], inv, h);
+    if (qvalid && h == 0) lse[(int64_t)blockIdx.y * Tn + q] = m + logf(ltot);
+}
+
+// =================================================================================================
+// delta[b,h,t] = sum_d dO.O   (rowsum(dP.P))
+// =================================================================================================
+template <typename T>
+__global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ delta,
+                                  int B, int Tn, int H, int D) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)B * H * Tn) return;
+    int t = (int)(gid % Tn);
+    int hd = (int)((gid / Tn) % H);
+    int b = (int)(gid / ((int64_t)Tn * H));
+    const int64_t off = ((int64_t)b * Tn + t) * (H * D) + hd * D;
+    constexpr int VN = Vec16<T>::N;
+    float a = 0.f;
+    for (int d = 0; d < D; d += VN) {
+        Vec16<T> x = ld16(o + off + d), y = ld16(d_o + off + d);
+#pragma unroll
+        for (int j = 0; j < VN; j++) a += x.get(j) * y.get(j);
+    }
+    delta[gid] = a;
+}
+
+// =================================================================================================
+// dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
+// =================================================================================================
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                      T* __restrict__ dqkv, int Tn, int H, float scale, DropCfg drop) {
+    using G = Geo<T, D>;
+    constexpr bool EXACT = AT<T>::EXACT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);
+    T* Vs = Ks + 64 * G::S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int b = blockIdx.y / H, hd = blockIdx.y % H;
+    const int E = H * D;
+    const int64_t rs = 3 * E;
+    const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
+    const T* kg = qg + E;
+    const T* vg = qg + 2 * E;
+    const T* dog = d_o + (int64_t)b * Tn * E + hd * D;
+    const int q0w = blockIdx.x * 128 + wave * 32;
+    const int q = q0w + (lane & 31);
+    const bool qvalid = q < Tn;
+    frag_t<T> qf[G::NS], dof[G::NS];
+    load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
+    load_bfrags<T, D>(dof, dog, E, q, qvalid, h);
+    const float lse_q = qvalid ? lse[(int64_t)blockIdx.y * Tn + q] : 0.f;
+    const float del_q = qvalid ? delta[(int64_t)blockIdx.y * Tn + q] : 0.f;
+    f32x16 dq[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dq[dt][r] = 0.f;
+    const int kv_end = min(Tn, blockIdx.x * 128 + 128);
+    const uint64_t drop_row = ((uint64_t)blockIdx.y * Tn + q) * (uint64_t)Tn;
+
+    for (int kt0 = 0; kt0 < kv_end; kt0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(Ks, kg, rs, kt0, Tn, 64, tid);
+        stage_rows<T, D>(Vs, vg, rs, kt0, Tn, 64, tid);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            const int k0 = kt0 + 32 * sub;
+            if (k0 > q0w + 31 || k0 >= Tn) continue;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+            s = mma_rows<T, D>(Ks, 32 * sub, qf, lane, s);
+            dp = mma_rows<T, D>(Vs, 32 * sub, dof, lane, dp);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int key = k0 + rho(r, h);
+                bool masked = (key > q) || (key >= Tn) || !qvalid;
+                float p = masked ? 0.f : exp_f<EXACT>(s[r] * scale - lse_q);
+                float dpv = dp[r];
+                if (drop.thr) dpv = apply_drop(drop, drop_row + (uint64_t)key, dpv);
+                s[r] = p * (dpv - del_q);
+            }
+#pragma unroll
+            for (int dt = 0; dt < G::DT; dt++) dq[dt] = mma_acc_b<T, D>(Ks, 32 * sub, dt, s, lane, dq[dt]);
+        }
+    }
+    T* dqg = dqkv + (int64_t)b * Tn * rs + hd * D;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale, h);
+}
+
+// =================================================================================================
+// dK, dV.  grid (ceil(T/128), B*H): wave w owns keys [kb*128 + 32w, +32); loops over query tiles >= its keys
+// =================================================================================================
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                       const float* __restrict__ lse, const float* __restrict__ delta,
+                                                       T* __restrict__ dqkv, int Tn, int H, float scale, DropCfg drop) {
+    using G = Geo<T, D>;
+    constexpr bool EXACT = AT<T>::EXACT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Qs = reinterpret_cast<T*>(smem_raw);          // [64][S]
+    T* Os = Qs + 64 * G::S;                          // dO [64][S]
+    float* Ls = reinterpret_cast<float*>(Os + 64 * G::S);   // lse [64]
+    float* Dl = Ls + 64;                             // delta [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int b = blockIdx.y / H, hd = blockIdx.y % H;
+    const int E = H * D;
+    const int64_t rs = 3 * E;
+    const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
+    const T* kg = qg + E;
+    const T* vg = qg + 2 * E;
+    const T* dog = d_o + (int64_t)b * Tn * E + hd * D;
+    const int k0w = blockIdx.x * 128 + wave * 32;
+    const int key = k0w + (lane & 31);
+    const bool kvalid = key < Tn;
+    frag_t<T> kf[G::NS], vf[G::NS];
+    load_bfrags<T, D>(kf, kg, rs, key, kvalid, h);
+    load_bfrags<T, D>(vf, vg, rs, key, kvalid, h);
+    f32x16 dk[G::DT], dv[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const uint64_t drop_bh = (uint64_t)blockIdx.y * Tn;
+
+    for (int qt0 = (blockIdx.x * 128) & ~63; qt0 < Tn; qt0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(Qs, qg, rs, qt0, Tn, 64, tid);
+        stage_rows<T, D>(Os, dog, E, qt0, Tn, 64, tid);
+        if (tid < 64) {
+            int qq = qt0 + tid;
+            Ls[tid] = qq < Tn ? lse[(int64_t)blockIdx.y * Tn + qq] : 0.f;
+            Dl[tid] = qq < Tn ? delta[(int64_t)blockIdx.y * Tn + qq] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            const int qb0 = qt0 + 32 * sub;
+            if (qb0 + 31 < k0w || qb0 >= Tn || k0w >= Tn) continue;     // wave-uniform: all (q, key) pairs masked
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+            s = mma_rows<T, D>(Qs, 32 * sub, kf, lane, s);              // S[q][key]
+            dp = mma_rows<T, D>(Os, 32 * sub, vf, lane, dp);            // dP[q][key]
+            f32x16 pt;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ql = 32 * sub + rho(r, h);
+                const int qq = qt0 + ql;
+                bool masked = (key > qq) || (qq >= Tn) || !kvalid;
+                float p = masked ? 0.f : exp_f<EXACT>(s[r] * scale - Ls[ql]);
+                float dpv = dp[r];
+                float pd = p;
+                if (drop.thr) {
+                    uint64_t idx = (drop_bh + (uint64_t)qq) * (uint64_t)Tn + (uint64_t)key;
+                    dpv = apply_drop(drop, idx, dpv);
+                    pd = apply_drop(drop, idx, p);
+                }
+                pt[r] = pd;                         // dropped probabilities feed dV
+                s[r] = p * (dpv - Dl[ql]);          // dS feeds dK
+            }
+#pragma unroll
+            for (int dt = 0; dt < G::DT; dt++) {
+                dv[dt] = mma_acc_b<T, D>(Os, 32 * sub, dt, pt, lane, dv[dt]);
+                dk[dt] = mma_acc_b<T, D>(Qs, 32 * sub, dt, s, lane, dk[dt]);
+            }
+        }
+    }
+    T* dkg = dqkv + (int64_t)b * Tn * rs + E + hd * D;
+    T* dvg = dkg + E;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; dt++) {
+        store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale, h);
+        store_t_tile<T, D>(dvg, rs, key, kvalid, dt, dv[dt], 1.0f, h);
+    }
+}
+
+// =================================================================================================
+// host launchers
+// =================================================================================================
+template <typename T, int D>
+static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
+    size_t smem = 2 * 64 * Geo<T, D>::S * sizeof(T);
+    dim3 grid(cdiv(Tn, 128), B * H);
+    attn_fwd_kernel<T, D><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+template <typename T, int D>
+static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                      void* dqkv, int B, int Tn, int H, float scale, DropCfg d) {
+    int64_t n = (int64_t)B * H * Tn;
+    attn_delta_kernel<T><<<(int)cdiv64(n, 256), 256, 0, s>>>((const T*)o, (const T*)d_o, delta, B, Tn, H, D);
+    KERNEL_CHECK();
+    dim3 grid(cdiv(Tn, 128), B * H);
+    size_t smem = 2 * 64 * Geo<T, D>::S * sizeof(T);
+    attn_dq_kernel<T, D><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    KERNEL_CHECK();
+    attn_dkv_kernel<T, D><<<grid, 256, smem + 128 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta,
+                                                                          (T*)dqkv, Tn, H, scale, d);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+#define DISPATCH_D(T, fn, ...)                                                         \
+    switch (D) {                                                                       \
+        case 16: return fn<T, 16>(__VA_ARGS__);                                        \
+        case 32: return fn<T, 32>(__VA_ARGS__);                                        \
+        case 64: return fn<T, 64>(__VA_ARGS__);                                        \
+        case 128: return fn<T, 128>(__VA_ARGS__);                                      \
+        default: cmp_set_error("attention: head size %d unsupported (16/32/64/128)", D); \
+                 return CMP_ERR_INVALID;                                               \
+    }
+
+extern "C" int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, int scale,
+                              int dtype, float p_drop, uint64_t seed, uint32_t rng_stream) {
+    if (B * T == 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    float sc = scale ? 1.0f / sqrtf((float)D) : 1.0f;
+    DropCfg d = make_drop(p_drop, seed, rng_stream);
+    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
+    else { DISPATCH_D(float, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
+}
+
+extern "C" int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
+                              float* delta_ws, void* dqkv, int B, int T, int H, int D, int scale, int dtype,
+                              float p_drop, uint64_t seed, uint32_t rng_stream) {
+    if (B * T == 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    float sc = scale ? 1.0f / sqrtf((float)D) : 1.0f;
+    DropCfg d = make_drop(p_drop, seed, rng_stream);
+    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d) }
+    else { DISPATCH_D(float, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d) }
+}

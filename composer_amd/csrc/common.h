@@ -1,0 +1,153 @@
+// common.h -- shared device/host helpers for libcomposer_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <algorithm>
+#include <math.h>
+#include <type_traits>
+
+#include "../../include/composer_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define WAVE 64
+
+// ---- error plumbing -----------------------------------------------------------------------------
+void cmp_set_error(const char* fmt, ...);
+
+#define HIP_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            cmp_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return CMP_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define CMP_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            cmp_set_error(__VA_ARGS__);             \
+            return CMP_ERR_INVALID;                 \
+        }                                           \
+    } while (0)
+
+#define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- dropout mask: bit-identical to oracle/transformer_oracle.py::dropout_keep -------------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t stream, uint64_t idx) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t h = mix32(lo ^ seed);
+    return mix32(h ^ (hi * 0x9E3779B1u) ^ stream);
+}
+static inline uint32_t drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    if (t < 0) t = 0;
+    return (uint32_t)t;
+}
+// site: 0 embed, 1 attention probabilities, 2 attn c_proj output, 3 mlp output
+static inline uint32_t drop_stream(int64_t step, int layer, int site) {
+    return (uint32_t)(((step * 64 + layer) * 4 + site) & 0xFFFFFFFFll);
+}
+
+struct DropCfg {
+    uint32_t thr;     // keep iff hash >= thr ; thr == 0 -> dropout disabled
+    uint32_t seed;
+    uint32_t stream;
+    float scale;      // 1/(1-p)
+};
+static inline DropCfg make_drop(float p, uint64_t seed, uint32_t stream) {
+    DropCfg d;
+    d.thr = p > 0.f ? drop_threshold(p) : 0u;
+    d.seed = (uint32_t)seed;
+    d.stream = stream;
+    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
+__device__ __forceinline__ float apply_drop(const DropCfg& d, uint64_t idx, float v) {
+    if (d.thr == 0u) return v;
+    return drop_hash(d.seed, d.stream, idx) >= d.thr ? v * d.scale : 0.0f;
+}
+
+// ---- numeric helpers ----------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+#define GELU_C 0.7978845608028654f   // sqrt(2/pi), transformer.py:40
+#define GELU_K 0.044715f
+
+template <bool EXACT> __device__ __forceinline__ float tanh_f(float x) {
+    if (EXACT) return tanhf(x);
+    // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
+    float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+template <bool EXACT> __device__ __forceinline__ float gelu_f(float x) {
+    float t = tanh_f<EXACT>(GELU_C * (x + GELU_K * x * x * x));
+    return 0.5f * x * (1.0f + t);
+}
+template <bool EXACT> __device__ __forceinline__ float gelu_grad_f(float x) {
+    float t = tanh_f<EXACT>(GELU_C * (x + GELU_K * x * x * x));
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * GELU_C * (1.0f + 3.0f * GELU_K * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// vector load/store of 8 (bf16) or 4 (fp32) contiguous elements = 16 bytes
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(Vec16<T>::v)*>(p) = r.v;
+}
+
+static inline size_t dtype_size(int dtype) { return dtype == CMP_BF16 ? 2 : 4; }

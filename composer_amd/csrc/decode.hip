@@ -1,0 +1,437 @@
+// decode.hip -- autoregressive decode: the loop of `composer generate` (cli.py:659-676) on one GPU.
+//
+// Two modes behind one per-token step:
+//   CMP_DECODE_LITERAL : cli.py as written -- `past` is never passed back, so every step after the first
+//                        feeds ONE token at position 0 with no context.
+//   CMP_DECODE_KV      : model(x, past=presents) (transformer.py:735-765, 423-426): one new token per step at
+//                        position P+i attending to a preallocated KV cache (the reference's tf.concat
+//                        re-allocates the cache every step).
+// The prompt goes through the batched forward of model.hip (prefill); each later token is a fixed chain of
+// 5L+2 small kernels whose only varying inputs (position, current token, RNG counter, output slot) live in
+// device memory, so the chain is captured ONCE into a hipGraph and replayed per token.
+//
+// Arithmetic is fp32 in both model dtypes (weights fp32 master, transposed once per decode_begin to
+// [N][K] so that a wave reads one output column as a contiguous, 16-B-per-lane stream).
+// Sampling: temperature <= 0 -> argmax, lowest index on ties (tf.argmax); otherwise Gumbel-max over
+// logits/temperature == a draw from softmax(logits/temperature) (tf.random.categorical, cli.py:671-673).
+#include "model.h"
+
+struct DecState {        // device-resident loop state
+    int pos;             // position id of the token about to be consumed
+    int token;           // that token
+    int produced;        // number of ids written to ids[]
+    int advance;         // 1: kv mode (pos += 1 per step), 0: literal (pos stays 0)
+    unsigned rng;        // sampling counter
+    int cap;             // capacity of ids[]
+    int W;               // wpe rows
+};
+
+struct DecLayerW {
+    float *attn_wT, *proj_wT, *fc_wT, *pr_wT;
+    float *kc, *vc;      // [H][W][D]
+};
+
+struct DecodeState {
+    DecState* st = nullptr;
+    int32_t* ids = nullptr;
+    float *x = nullptr, *u = nullptr, *qkv = nullptr, *att = nullptr, *r = nullptr, *g = nullptr, *logits = nullptr;
+    std::vector<DecLayerW> lw;
+    std::vector<void*> allocs;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int mode = 0;
+    float temperature = 0.f;
+    uint64_t seed = 0;
+    int produced = 0, returned = 0, cap = 0, pos = 0;
+    bool begun = false;
+};
+
+void decode_state_free(DecodeState* d) {
+    if (!d) return;
+    if (d->exec) hipGraphExecDestroy(d->exec);
+    if (d->graph) hipGraphDestroy(d->graph);
+    for (void* p : d->allocs) hipFree(p);
+    delete d;
+}
+
+template <typename Tp> static int dalloc(DecodeState* d, Tp** p, size_t bytes) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, bytes ? bytes : 16));
+    d->allocs.push_back(q);
+    *p = (Tp*)q;
+    return CMP_OK;
+}
+
+// out[n][k] = in[k][n]
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int K, int N) {
+    __shared__ float tile[32][33];
+    int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int k = k0 + j, n = n0 + tx;
+        tile[j][tx] = (k < K && n < N) ? in[(int64_t)k * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int n = n0 + j, k = k0 + tx;
+        if (n < N && k < K) out[(int64_t)n * K + k] = tile[tx][j];
+    }
+}
+
+// K/V of the prompt from the prefill's c_attn output [P][3E] (activation dtype) into the cache [H][W][D]
+template <typename T>
+__global__ void cache_fill_kernel(const T* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc, int P, int E,
+                                  int H, int D, int W) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * E) return;
+    int t = i / E, e = i % E, h = e / D, d = e % D;
+    kc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + E + e]);
+    vc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + 2 * E + e]);
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = -INFINITY;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s = fmaxf(s, red[w]);
+    return s;
+}
+
+// y[n] = act( LN?(x) . Wt[n,:] + bias[n] ) + resid[n];   16 columns per workgroup (4 waves x 4 columns)
+#define GV_CPW 4
+template <int ACT, bool LN_IN>
+__global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, float eps,
+                                                       const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ y,
+                                                       float* __restrict__ u_out, int K, int N) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [K] + 8
+    float* red = xs + K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (LN_IN) {
+        float s = 0.f;
+        for (int k = tid; k < K; k += 256) s += x[k];
+        float mu = block_sum(s, red) / (float)K;
+        float q = 0.f;
+        for (int k = tid; k < K; k += 256) { float d = x[k] - mu; q += d * d; }
+        float var = block_sum(q, red) / (float)K;
+        float rs = 1.0f / sqrtf(var + eps);
+        for (int k = tid; k < K; k += 256) {
+            float v = (x[k] - mu) * rs * ln_g[k] + ln_b[k];
+            xs[k] = v;
+            if (u_out && blockIdx.x == 0) u_out[k] = v;
+        }
+    } else {
+        for (int k = tid; k < K; k += 256) {
+            float v = x[k];
+            xs[k] = v;
+            if (u_out && blockIdx.x == 0) u_out[k] = v;
+        }
+    }
+    __syncthreads();
+    const int n0 = (blockIdx.x * 4 + wave) * GV_CPW;
+    float acc[GV_CPW];
+#pragma unroll
+    for (int c = 0; c < GV_CPW; c++) acc[c] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
+#pragma unroll
+        for (int c = 0; c < GV_CPW; c++) {
+            int n = n0 + c;
+            if (n < N) {
+                f32x4 wv = *reinterpret_cast<const f32x4*>(Wt + (int64_t)n * K + k);
+                acc[c] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < GV_CPW; c++) {
+        float v = wave_sum(acc[c]);
+        int n = n0 + c;
+        if (lane == 0 && n < N) {
+            if (bias) v += bias[n];
+            if (ACT == 1) v = gelu_f<true>(v);
+            if (resid) v += resid[n];
+            y[n] = v;
+        }
+    }
+}
+
+// one workgroup per head: append this token's k,v to the cache at st->pos, then softmax(q.K^T * scale).V
+__global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
+                                                       float* __restrict__ vc, float* __restrict__ att,
+                                                       const DecState* __restrict__ st, int E, int D, int W, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // q[D] | red[8] | scores[W] | part[256]
+    float* qs = sm;
+    float* red = sm + D;
+    float* sc = red + 8;
+    const int tid = threadIdx.x, h = blockIdx.x;
+    const int pos = st->pos;
+    float* kh = kc + (int64_t)h * W * D;
+    float* vh = vc + (int64_t)h * W * D;
+    if (tid < D) {
+        qs[tid] = qkv[h * D + tid];
+        kh[(int64_t)pos * D + tid] = qkv[E + h * D + tid];
+        vh[(int64_t)pos * D + tid] = qkv[2 * E + h * D + tid];
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int nk = pos + 1;
+    float mx = -INFINITY;
+    for (int j = tid; j < nk; j += 256) {
+        const float* kr = kh + (int64_t)j * D;
+        float a = 0.f;
+        for (int d = 0; d < D; d += 4) {
+            f32x4 kv = *reinterpret_cast<const f32x4*>(kr + d);
+            a += qs[d] * kv[0] + qs[d + 1] * kv[1] + qs[d + 2] * kv[2] + qs[d + 3] * kv[3];
+        }
+        a *= scale;
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int j = tid; j < nk; j += 256) {
+        float p = expf(sc[j] - mx);
+        sc[j] = p;
+        s += p;
+    }
+    s = block_sum(s, red);
+    __syncthreads();
+    const int groups = 256 / D;
+    const int g = tid / D, d = tid % D;
+    float o = 0.f;
+    for (int j = g; j < nk; j += groups) o += sc[j] * vh[(int64_t)j * D + d];
+    float* part = sc + W;
+    part[tid] = o;
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int gg = 0; gg < groups; gg++) t += part[gg * D + tid];
+        att[h * D + tid] = t / s;
+    }
+}
+
+// choose the next id from logits[V]; record it; build the next input embedding x = wte[id] + wpe[pos']
+__global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict__ logits, int ldz_row_off, int V,
+                                                         float temperature, unsigned seed, DecState* __restrict__ st,
+                                                         int32_t* __restrict__ ids, const float* __restrict__ wte,
+                                                         const float* __restrict__ wpe, float* __restrict__ x, int E,
+                                                         int first) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    __shared__ int chosen;
+    const int tid = threadIdx.x;
+    const float* z = logits + ldz_row_off;
+    const unsigned ctr = st->rng;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        float v = z[c];
+        if (temperature > 0.f) {
+            unsigned hsh = drop_hash(seed, 0xC0FFEEu + ctr, (uint64_t)c);
+            float u = ((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+            v = v / temperature - logf(-logf(u));
+        }
+        if (v > best) { best = v; arg = c; }
+    }
+    bv[tid] = best;
+    bi[tid] = arg;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            float ov = bv[tid + s];
+            int oi = bi[tid + s];
+            if (ov > bv[tid] || (ov == bv[tid] && oi < bi[tid])) { bv[tid] = ov; bi[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int id = bi[0];
+        chosen = id;
+        int n = st->produced;
+        if (n < st->cap) ids[n] = id;
+        st->produced = n + 1;
+        st->rng = ctr + 1;
+        st->token = id;
+        if (!first) st->pos = st->advance ? st->pos + 1 : 0;
+    }
+    __syncthreads();
+    const int id = chosen;
+    int pos = st->pos;             // written by tid 0 above, visible after the barrier
+    if (pos >= st->W) pos = st->W - 1;   // host refuses to step past the table; never index outside it
+    for (int e = tid; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)pos * E + e];
+}
+
+// -------------------------------------------------------------------------------------------------
+static int launch_gemv(hipStream_t s, int act, bool ln_in, const float* x, const float* g, const float* b, float eps,
+                       const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N) {
+    int grid = cdiv(N, 4 * GV_CPW);
+    size_t smem = (size_t)(K + 8) * 4;
+    if (act == 1) {
+        if (ln_in) dec_gemv_kernel<1, true><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
+        else dec_gemv_kernel<1, false><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
+    } else {
+        if (ln_in) dec_gemv_kernel<0, true><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
+        else dec_gemv_kernel<0, false><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
+    }
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+// one token: consumes d->x (embedding of st->token at st->pos), produces the next id and the next d->x
+static int enqueue_token_step(cmp_model* m, DecodeState* d) {
+    hipStream_t s = m->ctx->stream;
+    const int E = m->E, L = m->L;
+    const bool ln = m->cfg.use_layer_norm != 0;
+    const float eps = m->cfg.ln_eps;
+    const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->D) : 1.0f;
+    for (int i = 0; i < L; i++) {
+        const LayerOff& o = m->lo[i];
+        const DecLayerW& w = d->lw[i];
+        CHECK_RC(launch_gemv(s, 0, ln, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr, d->qkv,
+                             d->u, E, 3 * E));
+        size_t smem = (size_t)(m->D + 8 + m->W + 256) * 4;
+        dec_attn_kernel<<<m->H, 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, E, m->D, m->W, scale);
+        KERNEL_CHECK();
+        CHECK_RC(launch_gemv(s, 0, false, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, E, E));
+        CHECK_RC(launch_gemv(s, 1, ln, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
+                             nullptr, E, 4 * E));
+        CHECK_RC(launch_gemv(s, 0, false, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E));
+    }
+    CHECK_RC(launch_gemv(s, 0, true, d->x, m->P + m->off_lnf_g, m->P + m->off_lnf_b, eps, m->P + m->off_wte, nullptr, nullptr,
+                         d->logits, nullptr, E, m->V));
+    dec_sample_kernel<<<1, 256, 0, s>>>(d->logits, 0, m->V, d->temperature, (unsigned)d->seed, d->st, d->ids, m->P + m->off_wte,
+                                        m->P + m->off_wpe, d->x, E, 0);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int mode, float temperature, uint64_t seed) {
+    CMP_REQUIRE(m && prompt && P > 0, "decode_begin: prompt must hold at least one id");
+    CMP_REQUIRE(mode == CMP_DECODE_LITERAL || mode == CMP_DECODE_KV, "decode_begin: bad mode %d", mode);
+    CMP_REQUIRE(P <= m->W, "decode_begin: prompt length %d exceeds window_size %d", P, m->W);
+    for (int i = 0; i < P; i++)
+        CMP_REQUIRE(prompt[i] >= 0 && prompt[i] < m->V, "decode_begin: prompt id %d out of range [0,%d)", prompt[i], m->V);
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    hipStream_t s = m->ctx->stream;
+    if (m->dec) { HIP_CHECK(hipStreamSynchronize(s)); decode_state_free(m->dec); m->dec = nullptr; }
+    DecodeState* d = new DecodeState();
+    m->dec = d;
+    d->mode = mode;
+    d->temperature = temperature;
+    d->seed = seed;
+    d->cap = 1 << 16;
+    const int E = m->E, L = m->L, W = m->W;
+    CHECK_RC(dalloc(d, &d->st, sizeof(DecState)));
+    CHECK_RC(dalloc(d, &d->ids, (size_t)d->cap * 4));
+    CHECK_RC(dalloc(d, &d->x, (size_t)E * 4));
+    CHECK_RC(dalloc(d, &d->u, (size_t)E * 4));
+    CHECK_RC(dalloc(d, &d->qkv, (size_t)3 * E * 4));
+    CHECK_RC(dalloc(d, &d->att, (size_t)E * 4));
+    CHECK_RC(dalloc(d, &d->r, (size_t)E * 4));
+    CHECK_RC(dalloc(d, &d->g, (size_t)4 * E * 4));
+    CHECK_RC(dalloc(d, &d->logits, (size_t)m->ldz * 4));
+    d->lw.resize(L);
+    for (int i = 0; i < L; i++) {
+        const LayerOff& o = m->lo[i];
+        DecLayerW& w = d->lw[i];
+        CHECK_RC(dalloc(d, &w.attn_wT, (size_t)3 * E * E * 4));
+        CHECK_RC(dalloc(d, &w.proj_wT, (size_t)E * E * 4));
+        CHECK_RC(dalloc(d, &w.fc_wT, (size_t)4 * E * E * 4));
+        CHECK_RC(dalloc(d, &w.pr_wT, (size_t)4 * E * E * 4));
+        CHECK_RC(dalloc(d, &w.kc, (size_t)W * E * 4));
+        CHECK_RC(dalloc(d, &w.vc, (size_t)W * E * 4));
+        auto tr = [&](const float* in, float* out, int K, int N) {
+            dim3 grid(cdiv(N, 32), cdiv(K, 32));
+            transpose_kernel<<<grid, 256, 0, s>>>(in, out, K, N);
+        };
+        tr(m->P + o.attn_w, w.attn_wT, E, 3 * E);
+        tr(m->P + o.proj_w, w.proj_wT, E, E);
+        tr(m->P + o.fc_w, w.fc_wT, E, 4 * E);
+        tr(m->P + o.pr_w, w.pr_wT, 4 * E, E);
+        KERNEL_CHECK();
+    }
+    // prefill: the whole prompt through the batched forward (Transformer.call with past=None)
+    CHECK_RC(ensure_workspace(m, 1, P));
+    HIP_CHECK(hipMemcpyAsync(m->x_dev, prompt, (size_t)P * 4, hipMemcpyHostToDevice, s));
+    CHECK_RC(model_forward(m, m->x_dev, 1, P, false, 0));
+    if (mode == CMP_DECODE_KV) {
+        for (int i = 0; i < L; i++) {
+            int grid = cdiv(P * E, 256);
+            if (m->dtype == CMP_BF16)
+                cache_fill_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+            else
+                cache_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+            KERNEL_CHECK();
+        }
+    }
+    DecState h;
+    h.pos = (mode == CMP_DECODE_KV) ? P : 0;     // position of the first generated token when it is fed back
+    h.token = 0;
+    h.produced = 0;
+    h.advance = (mode == CMP_DECODE_KV) ? 1 : 0;
+    h.rng = 0;
+    h.cap = d->cap;
+    h.W = W;
+    HIP_CHECK(hipMemcpyAsync(d->st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    // first id from the last prompt row (cli.py:673 `[-1, 0]`)
+    dec_sample_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, temperature, (unsigned)seed, d->st, d->ids,
+                                        m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
+    KERNEL_CHECK();
+    HIP_CHECK(hipStreamSynchronize(s));
+    d->produced = 1;
+    d->returned = 0;
+    d->pos = h.pos;
+    // capture the per-token chain once
+    const char* nog = getenv("COMPOSER_NO_GRAPH");
+    if (!(nog && nog[0] == '1')) {
+        HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_token_step(m, d);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc != CMP_OK) return rc;
+        HIP_CHECK(e);
+        d->graph = g;
+        HIP_CHECK(hipGraphInstantiate(&d->exec, g, nullptr, nullptr, 0));
+    }
+    d->begun = true;
+    return CMP_OK;
+}
+
+extern "C" int cmp_decode_steps(cmp_model* m, int n, int32_t* ids_out) {
+    CMP_REQUIRE(m && ids_out && n >= 0, "decode_steps: bad arguments");
+    DecodeState* d = m->dec;
+    if (!d || !d->begun) {
+        cmp_set_error("decode_steps: call cmp_decode_begin first");
+        return CMP_ERR_STATE;
+    }
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    hipStream_t s = m->ctx->stream;
+    const int need = d->returned + n;
+    CMP_REQUIRE(need <= d->cap, "decode_steps: more than %d ids per decode_begin", d->cap);
+    while (d->produced < need) {
+        if (d->mode == CMP_DECODE_KV)
+            CMP_REQUIRE(d->pos < m->W, "decode_steps: position %d outside the wpe table (window_size %d): "
+                        "prompt_len + length - 1 must be <= window_size in kv-cache mode", d->pos, m->W);
+        if (d->exec) HIP_CHECK(hipGraphLaunch(d->exec, s));
+        else CHECK_RC(enqueue_token_step(m, d));
+        d->produced++;
+        if (d->mode == CMP_DECODE_KV) d->pos++;
+    }
+    HIP_CHECK(hipMemcpyAsync(ids_out, d->ids + d->returned, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    d->returned = need;
+    return CMP_OK;
+}

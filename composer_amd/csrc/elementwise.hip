@@ -1,0 +1,533 @@
+// elementwise.hip -- the HBM-bound kernels of the Transformer hot path (gfx950):
+// token+position embedding fwd/bwd, LayerNorm fwd/bwd, fused softmax-cross-entropy fwd+bwd,
+// Keras-formulation Adam, column sums (bias gradients).
+// Each kernel is one pass over its operands with 16-byte-per-lane coalesced accesses.
+#include "model.h"
+
+// =================================================================================================
+// Embedding: h[b,t,:] = wte[x[b,t],:] + wpe[pos0+t,:]  (+ dropout)      transformer.py:137-138,786,793-794
+// =================================================================================================
+template <typename T>
+__global__ void embed_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ wte,
+                                 const float* __restrict__ wpe, T* __restrict__ out, int ntok, int T_,
+                                 int E, int pos0, DropCfg drop) {
+    constexpr int VN = Vec16<T>::N;
+    const int chunks = E / VN;
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)ntok * chunks;
+    for (; gid < total; gid += (int64_t)gridDim.x * blockDim.x) {
+        int tok = (int)(gid / chunks);
+        int e0 = (int)(gid % chunks) * VN;
+        int id = ids[tok];
+        int t = tok % T_;
+        const float* a = wte + (int64_t)id * E + e0;
+        const float* p = wpe + (int64_t)(pos0 + t) * E + e0;
+        Vec16<T> r;
+#pragma unroll
+        for (int i = 0; i < VN; i += 4) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(a + i);
+            f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = av[j] + pv[j];
+                v = apply_drop(drop, (uint64_t)tok * E + e0 + i + j, v);
+                r.set(i + j, v);
+            }
+        }
+        st16(out + (int64_t)tok * E + e0, r);
+    }
+}
+
+// dwte[x[b,t],:] += dh[b,t,:] (f32 atomics, 256 contiguous bytes per wave-instruction);
+// dwpe[pos0+t,:] += sum_b dh[b,t,:].   One thread per (t, e); loops over b.
+template <typename T>
+__global__ void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dh,
+                                 float* __restrict__ dwte, float* __restrict__ dwpe, int B, int T_, int E,
+                                 int pos0, DropCfg drop) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)T_ * E) return;
+    int t = (int)(gid / E), e = (int)(gid % E);
+    float acc = 0.f;
+    for (int b = 0; b < B; b++) {
+        int tok = b * T_ + t;
+        float v = to_f32<T>(dh[(int64_t)tok * E + e]);
+        v = apply_drop(drop, (uint64_t)tok * E + e, v);
+        acc += v;
+        atomicAdd(dwte + (int64_t)ids[tok] * E + e, v);
+    }
+    dwpe[(int64_t)(pos0 + t) * E + e] += acc;
+}
+
+// =================================================================================================
+// LayerNorm (Keras non-fused path: biased variance, eps inside rsqrt)   transformer.py:551,563,694
+// one wave per row; a lane owns chunks (lane + 64*i) of 16 bytes.
+// =================================================================================================
+#define LN_MAXI 4
+template <typename T>
+__global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, T* __restrict__ y,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int E,
+                                     float eps) {
+    constexpr int VN = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int chunks = E / VN;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+        const T* xr = x + (int64_t)row * E;
+        Vec16<T> v[LN_MAXI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; i++) {
+            int c = lane + 64 * i;
+            if (c < chunks) {
+                v[i] = ld16(xr + c * VN);
+#pragma unroll
+                for (int j = 0; j < VN; j++) s += v[i].get(j);
+            }
+        }
+        float mu = wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; i++) {
+            int c = lane + 64 * i;
+            if (c < chunks) {
+#pragma unroll
+                for (int j = 0; j < VN; j++) {
+                    float d = v[i].get(j) - mu;
+                    q += d * d;
+                }
+            }
+        }
+        float var = wave_sum(q) / (float)E;
+        float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; i++) {
+            int c = lane + 64 * i;
+            if (c < chunks) {
+                Vec16<T> o;
+#pragma unroll
+                for (int j = 0; j < VN; j++) {
+                    int e = c * VN + j;
+                    o.set(j, (v[i].get(j) - mu) * rs * gamma[e] + beta[e]);
+                }
+                st16(y + (int64_t)row * E + c * VN, o);
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// dx = resid + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;  partial dgamma/dbeta per workgroup
+// into ws[wg][2][E]; ln_param_reduce_kernel folds them into dgamma/dbeta.
+template <typename T>
+__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, const T* __restrict__ resid,
+                                     T* __restrict__ dx, float* __restrict__ ws, int rows, int E) {
+    constexpr int VN = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [waves][2][E]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int chunks = E / VN;
+    float dg[LN_MAXI][VN], db[LN_MAXI][VN], gm[LN_MAXI][VN];
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; i++) {
+        int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < VN; j++) {
+            dg[i][j] = 0.f;
+            db[i][j] = 0.f;
+            gm[i][j] = (c < chunks) ? gamma[c * VN + j] : 0.f;
+        }
+    }
+    for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
+        const float mu = mean[row], rs = rstd[row];
+        Vec16<T> vdy[LN_MAXI], vx[LN_MAXI];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; i++) {
+            int c = lane + 64 * i;
+            if (c < chunks) {
+                vdy[i] = ld16(dy + (int64_t)row * E + c * VN);
+                vx[i] = ld16(x + (int64_t)row * E + c * VN);
+#pragma unroll
+                for (int j = 0; j < VN; j++) {
+                    float d = vdy[i].get(j);
+                    float xh = (vx[i].get(j) - mu) * rs;
+                    float g = d * gm[i][j];
+                    s1 += g;
+                    s2 += g * xh;
+                    dg[i][j] += d * xh;
+                    db[i][j] += d;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)E;
+        s2 = wave_sum(s2) / (float)E;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; i++) {
+            int c = lane + 64 * i;
+            if (c < chunks) {
+                Vec16<T> o, r;
+                if (resid) r = ld16(resid + (int64_t)row * E + c * VN);
+#pragma unroll
+                for (int j = 0; j < VN; j++) {
+                    float xh = (vx[i].get(j) - mu) * rs;
+                    float g = vdy[i].get(j) * gm[i][j];
+                    float v = rs * (g - s1 - xh * s2);
+                    if (resid) v += r.get(j);
+                    o.set(j, v);
+                }
+                st16(dx + (int64_t)row * E + c * VN, o);
+            }
+        }
+    }
+    // cross-wave reduction of the parameter-gradient partials
+    float* sm = ln_smem + (size_t)wave * 2 * E;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; i++) {
+        int c = lane + 64 * i;
+        if (c < chunks) {
+#pragma unroll
+            for (int j = 0; j < VN; j++) {
+                sm[c * VN + j] = dg[i][j];
+                sm[E + c * VN + j] = db[i][j];
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * E; e += blockDim.x) {
+        float a = 0.f;
+        for (int w = 0; w < wpb; w++) a += ln_smem[(size_t)w * 2 * E + e];
+        ws[(size_t)blockIdx.x * 2 * E + e] = a;
+    }
+}
+
+__global__ void ln_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int nparts, int E) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * E) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; p++) a += ws[(size_t)p * 2 * E + e];
+    if (e < E) dgamma[e] += a;
+    else dbeta[e - E] += a;
+}
+
+// =================================================================================================
+// softmax cross-entropy forward + backward in one pass     transformer.py:888,918,924-926
+// one wave per row.  loss_row = logsumexp(z) - z[y];  dz = (softmax(z) - onehot(y)) * inv_n
+// =================================================================================================
+#define XENT_MAXI 8   // vocab <= 512 columns (incl. padding)
+template <typename T>
+__global__ void softmax_xent_kernel(const float* __restrict__ z, int ldz, const int32_t* __restrict__ y,
+                                    T* __restrict__ dz, float* __restrict__ row_loss,
+                                    int32_t* __restrict__ row_correct, int rows, int V, float inv_n) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+        const float* zr = z + (int64_t)row * ldz;
+        float v[XENT_MAXI];
+        float mx = -INFINITY;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < XENT_MAXI; i++) {
+            int c = lane + 64 * i;
+            v[i] = (c < V) ? zr[c] : -INFINITY;
+            if (v[i] > mx) {   // strict > keeps the lowest index within the lane (columns ascend with i)
+                mx = v[i];
+                arg = c;
+            }
+        }
+        // wave argmax: larger value wins, ties -> lower index (tf.argmax)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float om = __shfl_xor(mx, o);
+            int oa = __shfl_xor(arg, o);
+            if (om > mx || (om == mx && oa < arg)) {
+                mx = om;
+                arg = oa;
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < XENT_MAXI; i++) {
+            int c = lane + 64 * i;
+            if (c < V) s += expf(v[i] - mx);
+        }
+        s = wave_sum(s);
+        float lse = mx + logf(s);
+        int yy = y[row];
+        if (dz) {
+            T* dr = dz + (int64_t)row * ldz;
+#pragma unroll
+            for (int i = 0; i < XENT_MAXI; i++) {
+                int c = lane + 64 * i;
+                if (c < ldz) {
+                    float g = 0.f;
+                    if (c < V) g = (expf(v[i] - lse) - (c == yy ? 1.0f : 0.0f)) * inv_n;
+                    dr[c] = from_f32<T>(g);
+                }
+            }
+        }
+        // z[y] lives in lane y&63, slot y>>6; select with static indices (a runtime-indexed v[] would go to scratch)
+        float zy2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < XENT_MAXI; i++) {
+            float cand = __shfl(v[i], yy & 63);
+            if (i == (yy >> 6)) zy2 = cand;
+        }
+        if (lane == 0) {
+            row_loss[row] = lse - zy2;
+            row_correct[row] = (arg == yy) ? 1 : 0;
+        }
+    }
+}
+
+// deterministic single-workgroup reduction of the per-row losses
+__global__ void metrics_reduce_kernel(const float* __restrict__ row_loss, const int32_t* __restrict__ row_correct,
+                                      int rows, Metrics* __restrict__ out) {
+    __shared__ double sl[256];
+    __shared__ long long sc[256];
+    double a = 0.0;
+    long long c = 0;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        a += (double)row_loss[i];
+        c += row_correct[i];
+    }
+    sl[threadIdx.x] = a;
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sl[threadIdx.x] += sl[threadIdx.x + s];
+            sc[threadIdx.x] += sc[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out->loss_sum = sl[0];
+        out->correct = sc[0];
+        out->loss_mean = (float)(sl[0] / (double)rows);
+        out->acc = (float)((double)sc[0] / (double)rows);
+    }
+}
+
+// =================================================================================================
+// Adam, Keras OptimizerV2 formulation (transformer.py:887,921):
+//   m += (g-m)(1-b1); v += (g^2-v)(1-b2); theta -= alpha*m/(sqrt(v)+eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t)
+// one flat pass over all parameters: reads theta,g,m,v (16 B/param) writes theta,m,v (12) [+2 bf16 shadow]
+// =================================================================================================
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n4, int64_t n,
+                            float alpha, float beta1, float beta2, float eps, float gscale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float gg = gv[j] * gscale;
+            mv[j] = beta1 * mv[j] + (1.0f - beta1) * gg;
+            vv[j] = beta2 * vv[j] + (1.0f - beta2) * gg * gg;
+            pv[j] = pv[j] - alpha * mv[j] / (sqrtf(vv[j]) + eps);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (shadow) {
+            bf16x4 s;
+#pragma unroll
+            for (int j = 0; j < 4; j++) s[j] = (bf16_t)pv[j];
+            reinterpret_cast<bf16x4*>(shadow)[i] = s;
+        }
+    }
+}
+
+__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 a = reinterpret_cast<const f32x4*>(in)[i];
+        bf16x4 s;
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[j] = (bf16_t)a[j];
+        reinterpret_cast<bf16x4*>(out)[i] = s;
+    }
+}
+
+// =================================================================================================
+// column sums (bias gradients): out[c] += sum_r X[r, c]
+// grid (ceil(cols/128), splits); 256 threads: lanes over 2 adjacent columns each, 4 waves over rows
+// =================================================================================================
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out, int rows, int cols) {
+    __shared__ float sm[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 128 + lane * 2;
+    const int rows_per = cdiv(rows, (int)gridDim.y);
+    const int r0 = blockIdx.y * rows_per;
+    const int r1 = min(rows, r0 + rows_per);
+    float a0 = 0.f, a1 = 0.f;
+    if (c0 < cols) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const T* p = X + (int64_t)r * ldx + c0;
+            a0 += to_f32<T>(p[0]);
+            if (c0 + 1 < cols) a1 += to_f32<T>(p[1]);
+        }
+    }
+    sm[wave][lane * 2] = a0;
+    sm[wave][lane * 2 + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        int c = blockIdx.x * 128 + threadIdx.x;
+        if (c < cols) {
+            float s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+            atomicAdd(out + c, s);
+        }
+    }
+}
+
+// =================================================================================================
+// host launchers (C ABI)
+// =================================================================================================
+extern "C" int cmp_k_embed_fwd(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out,
+                               int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed,
+                               uint32_t rng_stream) {
+    CMP_REQUIRE(E % 8 == 0, "embed_fwd: E=%d must be a multiple of 8", E);
+    hipStream_t s = (hipStream_t)stream;
+    DropCfg d = make_drop(p_drop, seed, rng_stream);
+    int ntok = B * T;
+    if (ntok == 0) return CMP_OK;
+    if (dtype == CMP_BF16) {
+        int64_t total = (int64_t)ntok * (E / 8);
+        int grid = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+        embed_fwd_kernel<bf16_t><<<grid, 256, 0, s>>>(ids, wte, wpe, (bf16_t*)out, ntok, T, E, pos0, d);
+    } else {
+        int64_t total = (int64_t)ntok * (E / 4);
+        int grid = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+        embed_fwd_kernel<float><<<grid, 256, 0, s>>>(ids, wte, wpe, (float*)out, ntok, T, E, pos0, d);
+    }
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+extern "C" int cmp_k_embed_bwd(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe,
+                               int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed,
+                               uint32_t rng_stream) {
+    hipStream_t s = (hipStream_t)stream;
+    DropCfg d = make_drop(p_drop, seed, rng_stream);
+    if (B * T == 0) return CMP_OK;
+    int grid = (int)cdiv64((int64_t)T * E, 256);
+    if (dtype == CMP_BF16)
+        embed_bwd_kernel<bf16_t><<<grid, 256, 0, s>>>(ids, (const bf16_t*)dh, dwte, dwpe, B, T, E, pos0, d);
+    else
+        embed_bwd_kernel<float><<<grid, 256, 0, s>>>(ids, (const float*)dh, dwte, dwpe, B, T, E, pos0, d);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+static int ln_check(int E, int dtype) {
+    int vn = dtype == CMP_BF16 ? 8 : 4;
+    CMP_REQUIRE(E % vn == 0 && E / vn <= 64 * LN_MAXI, "layernorm: E=%d unsupported for dtype %d (max %d)", E, dtype,
+                64 * LN_MAXI * vn);
+    return CMP_OK;
+}
+
+extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gamma, const float* beta, void* y,
+                                   float* mean, float* rstd, int rows, int E, float eps, int dtype) {
+    int rc = ln_check(E, dtype);
+    if (rc) return rc;
+    if (rows == 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = std::min(cdiv(rows, 4), 8192);
+    if (dtype == CMP_BF16)
+        layernorm_fwd_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, E, eps);
+    else
+        layernorm_fwd_kernel<float><<<grid, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, mean, rstd, rows, E, eps);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+static int ln_bwd_grid(int rows) { return std::max(1, std::min(cdiv(rows, 4), 512)); }
+
+extern "C" int64_t cmp_k_layernorm_bwd_ws(int rows, int E) { return (int64_t)ln_bwd_grid(rows) * 2 * E * sizeof(float); }
+
+extern "C" int cmp_k_layernorm_bwd(void* stream, const void* dy, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta,
+                                   void* ws, int rows, int E, int dtype) {
+    int rc = ln_check(E, dtype);
+    if (rc) return rc;
+    if (rows == 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = ln_bwd_grid(rows);
+    size_t smem = (size_t)4 * 2 * E * sizeof(float);
+    if (dtype == CMP_BF16)
+        layernorm_bwd_kernel<bf16_t><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                                                              (const bf16_t*)resid, (bf16_t*)dx, (float*)ws, rows, E);
+    else
+        layernorm_bwd_kernel<float><<<grid, 256, smem, s>>>((const float*)dy, (const float*)x, gamma, mean, rstd,
+                                                             (const float*)resid, (float*)dx, (float*)ws, rows, E);
+    KERNEL_CHECK();
+    ln_param_reduce_kernel<<<cdiv(2 * E, 256), 256, 0, s>>>((const float*)ws, dgamma, dbeta, grid, E);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+extern "C" int cmp_k_softmax_xent(void* stream, const float* logits, int ldz, const int32_t* y, void* dlogits,
+                                  float* row_loss, int32_t* row_correct, int rows, int V, float inv_n, int dtype) {
+    CMP_REQUIRE(ldz <= 64 * XENT_MAXI && V <= ldz, "softmax_xent: V=%d ldz=%d unsupported (max %d)", V, ldz, 64 * XENT_MAXI);
+    if (rows == 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = std::min(cdiv(rows, 4), 8192);
+    if (dtype == CMP_BF16)
+        softmax_xent_kernel<bf16_t><<<grid, 256, 0, s>>>(logits, ldz, y, (bf16_t*)dlogits, row_loss, row_correct, rows, V, inv_n);
+    else
+        softmax_xent_kernel<float><<<grid, 256, 0, s>>>(logits, ldz, y, (float*)dlogits, row_loss, row_correct, rows, V, inv_n);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics) {
+    metrics_reduce_kernel<<<1, 256, 0, s>>>(row_loss, row_correct, rows, (Metrics*)metrics);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+extern "C" int cmp_k_adam(void* stream, float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                          float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale) {
+    CMP_REQUIRE(n % 4 == 0, "adam: n=%lld must be a multiple of 4", (long long)n);
+    if (n == 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    double alpha = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    int64_t n4 = n / 4;
+    int grid = (int)std::min<int64_t>(cdiv64(n4, 256), 8192);
+    adam_kernel<<<grid, 256, 0, s>>>(p, g, m, v, (bf16_t*)shadow_bf16, n4, n, (float)alpha, beta1, beta2, eps, grad_scale);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n) {
+    if (n == 0) return CMP_OK;
+    int64_t n4 = n / 4;
+    int grid = (int)std::min<int64_t>(cdiv64(n4, 256), 8192);
+    cast_f32_to_bf16_kernel<<<grid, 256, 0, s>>>(in, (bf16_t*)out, n4);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+extern "C" int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype) {
+    if (rows == 0 || cols == 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int splits = std::max(1, std::min(rows / 256, 64));
+    dim3 grid(cdiv(cols, 128), splits);
+    if (dtype == CMP_BF16)
+        colsum_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, ldx, out, rows, cols);
+    else
+        colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)X, ldx, out, rows, cols);
+    KERNEL_CHECK();
+    return CMP_OK;
+}

@@ -1,0 +1,324 @@
+// gemm.hip -- dense contractions of the Transformer hot path on the gfx950 matrix cores.
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(k,n) )
+//
+// Replaces Conv1D.call (transformer.py:205-209), the tied-logits matmul (:139-144) and their
+// tape gradients (:920).  Operand storage (no data is ever transposed in HBM):
+//   ta=0: A stored [M,K] (K contiguous: forward X, dgrad dY)        ta=1: A stored [K,M] (wgrad X^T)
+//   tb=0: B stored [K,N] (N contiguous: Conv1D weight, wgrad dY)    tb=1: B stored [N,K] (dgrad W, logits wte)
+//
+// bf16 path: v_mfma_f32_16x16x32_bf16, 128x128x64 workgroup tile, 4 waves (2x2) of 64x64, LDS double buffer.
+//   K-contiguous operands : LDS image [row][64 k] (128-B rows, 16-B chunk XOR-swizzled by (row>>1)&7),
+//                           fragments by ds_read_b128 (conflict-free for the b128 lane groups).
+//   contraction-slow ones : LDS image [64 k][128 cols] (256-B rows, chunk XOR 2*((k&3)|((k>>3)&1)<<2)),
+//                           fragments by two ds_read_b64_tr_b16 (hardware transpose, conflict-free).
+// fp32 path (parity mode): v_mfma_f32_16x16x4_f32 = exact fp32 fma chains, 64x64x16 tile.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct Epilogue {
+    const float* bias;     // [N] or null
+    int act;               // 0 none, 1 gelu (pre-activation -> aux), 2 multiply by gelu'(aux)
+    void* aux;
+    int ldaux;
+    const void* resid;
+    int ldr;
+    int out_fp32;
+    int atomic;            // split-K: atomicAdd into fp32 C
+    DropCfg drop;
+};
+
+template <typename T, bool EXACT>
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, void* C, int ldc, int row, int col, float v) {
+    if (ep.atomic) {
+        atomicAdd((float*)C + (int64_t)row * ldc + col, v);
+        return;
+    }
+    if (ep.bias) v += ep.bias[col];
+    if (ep.act == 1) {
+        if (ep.aux) ((T*)ep.aux)[(int64_t)row * ep.ldaux + col] = from_f32<T>(v);
+        v = gelu_f<EXACT>(v);
+    } else if (ep.act == 2) {
+        v *= gelu_grad_f<EXACT>(to_f32<T>(((const T*)ep.aux)[(int64_t)row * ep.ldaux + col]));
+    }
+    v = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col, v);
+    if (ep.resid) v += to_f32<T>(((const T*)ep.resid)[(int64_t)row * ep.ldr + col]);
+    if (ep.out_fp32) ((float*)C)[(int64_t)row * ldc + col] = v;
+    else ((T*)C)[(int64_t)row * ldc + col] = from_f32<T>(v);
+}
+
+// =================================================================================================
+// fp32 (parity mode)
+// =================================================================================================
+#define F_BM 64
+#define F_BN 64
+#define F_BK 16
+#define F_LD 80   // LDS row stride in floats: 80 mod 32 = 16 -> the two k-rows of a 32-lane read group hit disjoint banks
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int64_t sam,
+                                                       int64_t sak, const float* __restrict__ B, int64_t sbk,
+                                                       int64_t sbn, void* C, int ldc, Epilogue ep, int ktiles_per_split) {
+    __shared__ float As[F_BK][F_LD];
+    __shared__ float Bs[F_BK][F_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * F_BM, n0 = blockIdx.x * F_BN;
+    const int nk = cdiv(K, F_BK);
+    const int kt0 = blockIdx.z * ktiles_per_split;
+    const int kt1 = min(nk, kt0 + ktiles_per_split);
+    const bool a_kc = (sak == 1), b_kc = (sbk == 1);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int k0 = kt * F_BK;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int idx = tid + 256 * i;
+            int m, k;
+            if (a_kc) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
+            ra[i] = (m0 + m < M && k0 + k < K) ? A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak] : 0.f;
+            int n;
+            if (b_kc) { n = idx >> 4; k = idx & 15; } else { k = idx >> 6; n = idx & 63; }
+            rb[i] = (n0 + n < N && k0 + k < K) ? B[(int64_t)(k0 + k) * sbk + (int64_t)(n0 + n) * sbn] : 0.f;
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int idx = tid + 256 * i;
+            int m, k;
+            if (a_kc) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
+            As[k][m] = ra[i];
+            int n;
+            if (b_kc) { n = idx >> 4; k = idx & 15; } else { k = idx >> 6; n = idx & 63; }
+            Bs[k][n] = rb[i];
+        }
+    };
+
+    if (kt0 < kt1) gload(kt0);
+    for (int kt = kt0; kt < kt1; kt++) {
+        __syncthreads();
+        swrite();
+        __syncthreads();
+        if (kt + 1 < kt1) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < F_BK / 4; ks++) {
+            const int kk = ks * 4 + (lane >> 4);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                a[i] = As[kk][wm * 32 + i * 16 + (lane & 15)];
+                b[i] = Bs[kk][wn * 32 + i * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+                int col = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (row < M && col < N) epilogue_store<float, true>(ep, C, ldc, row, col, acc[i][j][r]);
+            }
+}
+
+// =================================================================================================
+// bf16
+// =================================================================================================
+#define G_BM 128
+#define G_BN 128
+#define G_BK 64
+#define G_IMG (128 * 64 * 2)   // bytes per operand image
+
+// K-major image [128 rows][64 k]: byte offset of 16-B chunk c (0..7) of row r
+__device__ __forceinline__ int kmaj_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+// contraction-slow image [64 k][128 cols]: byte offset of 16-B chunk c (0..15) of k-row k
+__device__ __forceinline__ int cslow_off(int k, int c) { return k * 256 + ((c ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1)) << 4); }
+
+template <bool KMAJOR>
+__device__ __forceinline__ void g_load_tile(bf16x8 (&r)[4], const bf16_t* __restrict__ P, int64_t ld, int row0, int nrows,
+                                            int k0, int K, int tid) {
+    // KMAJOR: P[(row0+row)*ld + k]; rows = tile's M/N index.   else: P[(k0+k)*ld + row0 + col]
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int q = tid + 256 * i;
+        bf16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; j++) z[j] = (bf16_t)0.f;
+        if (KMAJOR) {
+            int row = q >> 3, c = q & 7;
+            bool ok = (row0 + row < nrows) && (k0 + c * 8 < K);
+            r[i] = ok ? *reinterpret_cast<const bf16x8*>(P + (int64_t)(row0 + row) * ld + k0 + c * 8) : z;
+        } else {
+            int k = q >> 4, c = q & 15;
+            bool ok = (k0 + k < K) && (row0 + c * 8 < nrows);
+            r[i] = ok ? *reinterpret_cast<const bf16x8*>(P + (int64_t)(k0 + k) * ld + row0 + c * 8) : z;
+        }
+    }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void g_store_tile(const bf16x8 (&r)[4], char* img, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int q = tid + 256 * i;
+        int off = KMAJOR ? kmaj_off(q >> 3, q & 7) : cslow_off(q >> 4, q & 15);
+        *reinterpret_cast<bf16x8*>(img + off) = r[i];
+    }
+}
+// fragment for one 16-row (or 16-col) tile `t16` (index within the 128-wide image) and 32-deep k-step ks
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 g_frag(const char* img, int t16, int ks, int lane) {
+    if (KMAJOR) {
+        int row = t16 * 16 + (lane & 15);
+        int c = ks * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(img + kmaj_off(row, c));
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int k = ks * 32 + 8 * g + q;
+        const int c = t16 * 2 + (p >> 1);
+        const int sub = (p & 1) * 8;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off(k, c) + sub));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off(k + 4, c) + sub));
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f[j] = lo[j];
+            f[4 + j] = hi[j];
+        }
+        return f;
+    }
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int64_t lda,
+                                                        const bf16_t* __restrict__ B, int64_t ldb, void* C, int ldc,
+                                                        Epilogue ep, int ktiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A img | B img]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+    const int nk = cdiv(K, G_BK);
+    const int kt0 = blockIdx.z * ktiles_per_split;
+    const int kt1 = min(nk, kt0 + ktiles_per_split);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 ra[4], rb[4];
+    if (kt0 < kt1) {
+        g_load_tile<A_KM>(ra, A, lda, m0, M, kt0 * G_BK, K, tid);
+        g_load_tile<B_KM>(rb, B, ldb, n0, N, kt0 * G_BK, K, tid);
+        g_store_tile<A_KM>(ra, smem, tid);
+        g_store_tile<B_KM>(rb, smem + G_IMG, tid);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; kt++) {
+        const int st = (kt - kt0) & 1;
+        const char* ia = smem + st * 2 * G_IMG;
+        const char* ib = ia + G_IMG;
+        const bool more = kt + 1 < kt1;
+        if (more) {
+            g_load_tile<A_KM>(ra, A, lda, m0, M, (kt + 1) * G_BK, K, tid);
+            g_load_tile<B_KM>(rb, B, ldb, n0, N, (kt + 1) * G_BK, K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                fa[i] = g_frag<A_KM>(ia, wm * 4 + i, ks, lane);
+                fb[i] = g_frag<B_KM>(ib, wn * 4 + i, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* na = smem + (st ^ 1) * 2 * G_IMG;
+            g_store_tile<A_KM>(ra, na, tid);
+            g_store_tile<B_KM>(rb, na + G_IMG, tid);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                int col = n0 + wn * 64 + j * 16 + (lane & 15);
+                if (row < M && col < N) epilogue_store<bf16_t, false>(ep, C, ldc, row, col, acc[i][j][r]);
+            }
+}
+
+// =================================================================================================
+// host launcher
+// =================================================================================================
+extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda,
+                          const void* Bm, int ldb, void* C, int ldc, const float* bias, int act, void* aux, int ldaux,
+                          const void* resid, int ldr, int out_fp32, int splitk, float p_drop, uint64_t seed,
+                          uint32_t rng_stream) {
+    if (M == 0 || N == 0) return CMP_OK;
+    CMP_REQUIRE(K > 0, "gemm: K must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    Epilogue ep;
+    ep.bias = bias;
+    ep.act = act;
+    ep.aux = aux;
+    ep.ldaux = ldaux;
+    ep.resid = resid;
+    ep.ldr = ldr;
+    ep.out_fp32 = out_fp32;
+    ep.atomic = splitk > 1 ? 1 : 0;
+    ep.drop = make_drop(p_drop, seed, rng_stream);
+    if (splitk > 1)
+        CMP_REQUIRE(out_fp32 && !bias && act == 0 && !resid && p_drop == 0.f,
+                    "gemm: split-K needs a plain fp32 accumulate epilogue");
+    CMP_REQUIRE(act == 0 || aux != nullptr || act == 1, "gemm: act=2 needs aux");
+    if (dtype == CMP_FP32) {
+        int nk = cdiv(K, F_BK);
+        splitk = std::max(1, std::min(splitk, nk));
+        int per = cdiv(nk, splitk);
+        dim3 grid(cdiv(N, F_BN), cdiv(M, F_BM), cdiv(nk, per));
+        int64_t sam = ta ? 1 : lda, sak = ta ? lda : 1;
+        int64_t sbk = tb ? 1 : ldb, sbn = tb ? ldb : 1;
+        gemm_f32_kernel<<<grid, 256, 0, s>>>(M, N, K, (const float*)A, sam, sak, (const float*)Bm, sbk, sbn, C, ldc, ep, per);
+    } else {
+        CMP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm(bf16): leading dimensions must be multiples of 8 (lda=%d ldb=%d)", lda, ldb);
+        CMP_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)Bm & 15) == 0, "gemm(bf16): operands must be 16-byte aligned");
+        int nk = cdiv(K, G_BK);
+        splitk = std::max(1, std::min(splitk, nk));
+        int per = cdiv(nk, splitk);
+        dim3 grid(cdiv(N, G_BN), cdiv(M, G_BM), cdiv(nk, per));
+        size_t smem = 4 * G_IMG;
+        const bf16_t* a = (const bf16_t*)A;
+        const bf16_t* b = (const bf16_t*)Bm;
+        // A_KM = !ta ; B_KM = tb
+        if (!ta && !tb) gemm_bf16_kernel<true, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
+        else if (!ta && tb) gemm_bf16_kernel<true, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
+        else if (ta && !tb) gemm_bf16_kernel<false, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
+        else gemm_bf16_kernel<false, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
+    }
+    KERNEL_CHECK();
+    return CMP_OK;
+}

@@ -1,0 +1,109 @@
+// model.h -- shared definitions of the device-resident model state (see model.hip for the layout notes)
+#pragma once
+#include "common.h"
+#include <rccl/rccl.h>
+#include <vector>
+#include <string>
+#include <map>
+
+struct DecodeState;
+
+struct Metrics {
+    double loss_sum;
+    long long correct;
+    float loss_mean;
+    float acc;
+};
+
+#define NCCL_CHECK(expr)                                                                         \
+    do {                                                                                         \
+        ncclResult_t _r = (expr);                                                                \
+        if (_r != ncclSuccess) {                                                                 \
+            cmp_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+            return CMP_ERR_RCCL;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+#define CHECK_RC(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != CMP_OK) return _rc; \
+    } while (0)
+
+struct cmp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute
+    hipStream_t comm_stream = nullptr;  // RCCL
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+struct ParamInfo {
+    std::string name;
+    int rank;
+    int64_t shape[4];
+    int64_t numel;
+    int64_t offset;
+};
+
+struct LayerOff {   // element offsets into the flat buffers
+    int64_t ln1_g, ln1_b, attn_w, attn_b, proj_w, proj_b, ln2_g, ln2_b, fc_w, fc_b, pr_w, pr_b;
+    int64_t begin, end;
+};
+
+struct LayerAct {
+    void *u, *qkv, *att, *r, *n, *fc, *g;
+    float *ln1_mean, *ln1_rstd, *ln2_mean, *ln2_rstd, *lse;
+};
+
+struct cmp_model {
+    cmp_ctx* ctx = nullptr;
+    cmp_model_cfg cfg;
+    int V, E, W, L, H, D, ldz;
+    int dtype;
+    size_t es;                 // activation element size
+    std::vector<ParamInfo> params;
+    std::map<std::string, int> index;
+    int64_t total = 0;         // elements in the flat buffers
+    int64_t off_wte = 0, off_wpe = 0, off_lnf_g = 0, off_lnf_b = 0;
+    std::vector<LayerOff> lo;
+    float *P = nullptr, *G = nullptr, *Am = nullptr, *Av = nullptr;
+    bf16_t* S = nullptr;       // bf16 shadow (bf16 mode)
+    int64_t iterations = 0;
+    // workspace
+    int capB = 0, capT = 0;
+    std::vector<void*> allocs;
+    std::vector<void*> xs;     // L+1 residual-stream tensors
+    std::vector<LayerAct> act;
+    void *hf = nullptr, *dlogits = nullptr;
+    float *logits = nullptr, *lnf_mean = nullptr, *lnf_rstd = nullptr, *row_loss = nullptr, *delta = nullptr;
+    int32_t *row_correct = nullptr, *x_dev = nullptr, *y_dev = nullptr;
+    void *dx = nullptr, *dr = nullptr, *tmpE = nullptr, *dmask = nullptr, *dfc = nullptr, *dqkv = nullptr;
+    void* ln_ws = nullptr;
+    Metrics* metrics = nullptr;        // device
+    Metrics* metrics_host = nullptr;   // pinned
+    float* dp_metrics = nullptr;       // device [2] for the cross-rank mean
+    std::vector<hipEvent_t> bucket_ev; // L+2 events
+    hipEvent_t comm_done = nullptr;
+    DecodeState* dec = nullptr;
+
+    const void* w(int64_t off) const { return dtype == CMP_BF16 ? (const void*)(S + off) : (const void*)(P + off); }
+};
+
+
+template <typename Tp> static int dev_alloc(cmp_model* m, Tp** p, size_t bytes) {
+    void* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, bytes ? bytes : 16));
+    m->allocs.push_back(q);
+    *p = (Tp*)q;
+    return CMP_OK;
+}
+
+// elementwise.hip
+int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics);
+int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n);
+// model.hip
+int ensure_workspace(cmp_model* m, int B, int T);
+int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step);
+// decode.hip
+void decode_state_free(DecodeState* d);

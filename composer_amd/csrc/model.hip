@@ -1,0 +1,569 @@
+// model.hip -- cmp_ctx / cmp_model: device-resident state of the Transformer hot path and the native
+// train / eval / forward drivers that chain the HIP kernels on one stream (no Python between kernels).
+//
+// Reference path: Transformer.call (transformer.py:696-833), DecoderBlock.call (:574-597),
+// the train-loop body (:914-930) and Keras Adam (:887,921).
+//
+// HBM layout
+//   params / grads / adam_m / adam_v : ONE flat fp32 buffer each, tensors in checkpoint order
+//     (wte, wpe, block 0..L-1, ln_f), every tensor offset a multiple of 8 elements; in bf16 mode a flat bf16
+//     shadow with identical offsets is rewritten by the Adam kernel.  A decoder block is one contiguous
+//     range => one RCCL all-reduce bucket per block, issued on the side stream as soon as that block's
+//     backward has been enqueued.
+//   activations: row-major [B*T, width] in the activation dtype; saved per layer for backward:
+//     x_in, u=LN1(x_in), qkv, att, r=u+proj, n=LN2(r), fc (pre-GELU), g=gelu(fc); LN stats and LSE in fp32.
+#include "model.h"
+#include <stdarg.h>
+
+static thread_local char g_err[1024] = "";
+void cmp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* cmp_last_error(void) { return g_err; }
+extern "C" int cmp_version(void) { return 1; }
+extern "C" int cmp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// -------------------------------------------------------------------------------------------------
+// context
+// -------------------------------------------------------------------------------------------------
+extern "C" int cmp_ctx_create(int device, cmp_ctx** out) {
+    CMP_REQUIRE(out != nullptr, "ctx_create: out is null");
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    CMP_REQUIRE(device >= 0 && device < n, "ctx_create: device %d not present (%d visible)", device, n);
+    HIP_CHECK(hipSetDevice(device));
+    cmp_ctx* c = new cmp_ctx();
+    c->device = device;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    *out = c;
+    return CMP_OK;
+}
+extern "C" int cmp_ctx_destroy(cmp_ctx* c) {
+    if (!c) return CMP_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    if (c->comm) ncclCommDestroy(c->comm);
+    hipStreamDestroy(c->stream);
+    hipStreamDestroy(c->comm_stream);
+    delete c;
+    return CMP_OK;
+}
+extern "C" int cmp_sync(cmp_ctx* c) {
+    CMP_REQUIRE(c, "sync: ctx is null");
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->comm_stream));
+    return CMP_OK;
+}
+extern "C" void* cmp_ctx_stream(cmp_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int cmp_dp_unique_id(void* id128) {
+    CMP_REQUIRE(id128, "dp_unique_id: null buffer");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCL_CHECK(ncclGetUniqueId(&id));
+    memcpy(id128, &id, 128);
+    return CMP_OK;
+}
+extern "C" int cmp_dp_init(cmp_ctx* c, int rank, int nranks, const void* id128) {
+    CMP_REQUIRE(c && id128 && nranks >= 1 && rank >= 0 && rank < nranks, "dp_init: bad arguments");
+    CMP_REQUIRE(c->comm == nullptr, "dp_init: communicator already initialised");
+    HIP_CHECK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->rank = rank;
+    c->nranks = nranks;
+    return CMP_OK;
+}
+extern "C" int cmp_dp_allreduce_test(cmp_ctx* c, float* host_inout, int n) {
+    CMP_REQUIRE(c && c->comm, "dp_allreduce_test: communicator not initialised");
+    float* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
+    HIP_CHECK(hipMemcpy(d, host_inout, (size_t)n * 4, hipMemcpyHostToDevice));
+    NCCL_CHECK(ncclAllReduce(d, d, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
+    HIP_CHECK(hipStreamSynchronize(c->comm_stream));
+    HIP_CHECK(hipMemcpy(host_inout, d, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipFree(d));
+    return CMP_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// model construction
+// -------------------------------------------------------------------------------------------------
+static int64_t add_param(cmp_model* m, const std::string& name, int rank, int64_t d0, int64_t d1) {
+    ParamInfo p;
+    p.name = name;
+    p.rank = rank;
+    p.shape[0] = d0;
+    p.shape[1] = d1;
+    p.shape[2] = p.shape[3] = 1;
+    p.numel = d0 * (rank > 1 ? d1 : 1);
+    p.offset = m->total;
+    m->total += (p.numel + 7) / 8 * 8;
+    m->index[name] = (int)m->params.size();
+    m->params.push_back(p);
+    return p.offset;
+}
+
+
+extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_model** out) {
+    CMP_REQUIRE(ctx && cfg && out, "model_create: null argument");
+    const int V = cfg->vocab_size, E = cfg->embedding_size, W = cfg->window_size, L = cfg->layers, H = cfg->heads;
+    CMP_REQUIRE(V > 0 && E > 0 && W > 0 && L > 0 && H > 0, "model_create: sizes must be positive");
+    CMP_REQUIRE(E % H == 0, "model_create: embedding_size %d not divisible by heads %d (transformer.py:255)", E, H);
+    CMP_REQUIRE(E % 8 == 0, "model_create: embedding_size %d must be a multiple of 8", E);
+    const int D = E / H;
+    CMP_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, "model_create: head size %d unsupported (16/32/64/128)", D);
+    CMP_REQUIRE(V <= 512, "model_create: vocab_size %d > 512 unsupported by the fused softmax-xent kernel", V);
+    CMP_REQUIRE(cfg->dtype == CMP_FP32 || cfg->dtype == CMP_BF16, "model_create: bad dtype %d", cfg->dtype);
+    CMP_REQUIRE(L < 64, "model_create: at most 63 layers");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    cmp_model* m = new cmp_model();
+    m->ctx = ctx;
+    m->cfg = *cfg;
+    m->V = V; m->E = E; m->W = W; m->L = L; m->H = H; m->D = D;
+    m->ldz = (V + 63) / 64 * 64;
+    m->dtype = cfg->dtype;
+    m->es = dtype_size(cfg->dtype);
+    m->off_wte = add_param(m, "wte/weight", 2, V, E);
+    m->off_wpe = add_param(m, "wpe/embeddings", 2, W, E);
+    m->lo.resize(L);
+    for (int i = 0; i < L; i++) {
+        std::string p = "decoder_blocks/" + std::to_string(i) + "/";
+        LayerOff& o = m->lo[i];
+        o.begin = m->total;
+        o.ln1_g = add_param(m, p + "ln_1/gamma", 1, E, 1);
+        o.ln1_b = add_param(m, p + "ln_1/beta", 1, E, 1);
+        o.attn_w = add_param(m, p + "attn/c_attn/weight", 2, E, 3 * E);
+        o.attn_b = add_param(m, p + "attn/c_attn/bias", 2, 1, 3 * E);
+        o.proj_w = add_param(m, p + "attn/c_proj/weight", 2, E, E);
+        o.proj_b = add_param(m, p + "attn/c_proj/bias", 2, 1, E);
+        o.ln2_g = add_param(m, p + "ln_2/gamma", 1, E, 1);
+        o.ln2_b = add_param(m, p + "ln_2/beta", 1, E, 1);
+        o.fc_w = add_param(m, p + "mlp/c_fc/weight", 2, E, 4 * E);
+        o.fc_b = add_param(m, p + "mlp/c_fc/bias", 2, 1, 4 * E);
+        o.pr_w = add_param(m, p + "mlp/c_proj/weight", 2, 4 * E, E);
+        o.pr_b = add_param(m, p + "mlp/c_proj/bias", 2, 1, E);
+        o.end = m->total;
+    }
+    m->off_lnf_g = add_param(m, "ln_f/gamma", 1, E, 1);
+    m->off_lnf_b = add_param(m, "ln_f/beta", 1, E, 1);
+    size_t bytes = (size_t)m->total * 4;
+    CHECK_RC(dev_alloc(m, &m->P, bytes));
+    CHECK_RC(dev_alloc(m, &m->G, bytes));
+    CHECK_RC(dev_alloc(m, &m->Am, bytes));
+    CHECK_RC(dev_alloc(m, &m->Av, bytes));
+    HIP_CHECK(hipMemsetAsync(m->P, 0, bytes, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(m->G, 0, bytes, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(m->Am, 0, bytes, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(m->Av, 0, bytes, ctx->stream));
+    if (m->dtype == CMP_BF16) {
+        CHECK_RC(dev_alloc(m, &m->S, (size_t)m->total * 2));
+        HIP_CHECK(hipMemsetAsync(m->S, 0, (size_t)m->total * 2, ctx->stream));
+    }
+    CHECK_RC(dev_alloc(m, &m->metrics, sizeof(Metrics)));
+    CHECK_RC(dev_alloc(m, &m->dp_metrics, 16));
+    HIP_CHECK(hipHostMalloc((void**)&m->metrics_host, sizeof(Metrics), hipHostMallocDefault));
+    memset(m->metrics_host, 0, sizeof(Metrics));
+    m->bucket_ev.resize(L + 2);
+    for (auto& e : m->bucket_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&m->comm_done, hipEventDisableTiming));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = m;
+    return CMP_OK;
+}
+
+extern "C" int cmp_model_destroy(cmp_model* m) {
+    if (!m) return CMP_OK;
+    hipSetDevice(m->ctx->device);
+    hipDeviceSynchronize();
+    if (m->dec) decode_state_free(m->dec);
+    for (void* p : m->allocs) hipFree(p);
+    if (m->metrics_host) hipHostFree(m->metrics_host);
+    for (auto& e : m->bucket_ev) hipEventDestroy(e);
+    if (m->comm_done) hipEventDestroy(m->comm_done);
+    delete m;
+    return CMP_OK;
+}
+
+extern "C" int cmp_param_count(cmp_model* m, int* n) {
+    CMP_REQUIRE(m && n, "param_count: null");
+    *n = (int)m->params.size();
+    return CMP_OK;
+}
+extern "C" int cmp_param_info(cmp_model* m, int i, const char** name, int* rank, int64_t shape[4], int64_t* numel) {
+    CMP_REQUIRE(m && i >= 0 && i < (int)m->params.size(), "param_info: index %d out of range", i);
+    const ParamInfo& p = m->params[i];
+    if (name) *name = p.name.c_str();
+    if (rank) *rank = p.rank;
+    if (shape) for (int k = 0; k < 4; k++) shape[k] = p.shape[k];
+    if (numel) *numel = p.numel;
+    return CMP_OK;
+}
+static float* kind_buf(cmp_model* m, int kind) {
+    switch (kind) {
+        case 0: return m->P;
+        case 1: return m->Am;
+        case 2: return m->Av;
+        case 3: return m->G;
+    }
+    return nullptr;
+}
+extern "C" int cmp_param_get(cmp_model* m, const char* name, int kind, float* host, int64_t numel) {
+    CMP_REQUIRE(m && name && host, "param_get: null");
+    auto it = m->index.find(name);
+    CMP_REQUIRE(it != m->index.end(), "param_get: unknown parameter '%s'", name);
+    const ParamInfo& p = m->params[it->second];
+    CMP_REQUIRE(numel == p.numel, "param_get: '%s' has %lld elements, caller passed %lld", name, (long long)p.numel, (long long)numel);
+    float* b = kind_buf(m, kind);
+    CMP_REQUIRE(b, "param_get: bad kind %d", kind);
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(m->ctx->comm_stream));
+    HIP_CHECK(hipMemcpy(host, b + p.offset, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return CMP_OK;
+}
+extern "C" int cmp_param_set(cmp_model* m, const char* name, int kind, const float* host, int64_t numel) {
+    CMP_REQUIRE(m && name && host, "param_set: null");
+    auto it = m->index.find(name);
+    CMP_REQUIRE(it != m->index.end(), "param_set: unknown parameter '%s'", name);
+    const ParamInfo& p = m->params[it->second];
+    CMP_REQUIRE(numel == p.numel, "param_set: '%s' has %lld elements, caller passed %lld", name, (long long)p.numel, (long long)numel);
+    float* b = kind_buf(m, kind);
+    CMP_REQUIRE(b, "param_set: bad kind %d", kind);
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    HIP_CHECK(hipMemcpy(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice));
+    if (kind == 0 && m->S) {
+        int64_t n8 = (p.numel + 7) / 8 * 8;
+        CHECK_RC(launch_cast_bf16(m->ctx->stream, m->P + p.offset, m->S + p.offset, n8));
+        HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
+    return CMP_OK;
+}
+extern "C" int cmp_adam_iter_get(cmp_model* m, int64_t* it) {
+    CMP_REQUIRE(m && it, "adam_iter_get: null");
+    *it = m->iterations;
+    return CMP_OK;
+}
+extern "C" int cmp_adam_iter_set(cmp_model* m, int64_t it) {
+    CMP_REQUIRE(m && it >= 0, "adam_iter_set: bad value");
+    m->iterations = it;
+    return CMP_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// workspace
+// -------------------------------------------------------------------------------------------------
+int ensure_workspace(cmp_model* m, int B, int T) {
+    CMP_REQUIRE(B > 0 && T > 0, "batch and sequence must be positive (B=%d T=%d)", B, T);
+    CMP_REQUIRE(T <= m->W, "sequence length %d exceeds window_size %d (wpe rows, transformer.py:675-679)", T, m->W);
+    if (m->capB * m->capT >= B * T && m->capB > 0) return CMP_OK;
+    CMP_REQUIRE(m->capB == 0, "workspace was sized for %d tokens; create the model with max_batch/max_seq covering B=%d T=%d",
+                m->capB * m->capT, B, T);
+    // size for the larger of (this call, cfg.max_batch*max_seq)
+    int64_t M = (int64_t)B * T;
+    int64_t Mcfg = (int64_t)std::max(1, m->cfg.max_batch) * std::max(1, std::min(m->cfg.max_seq, m->W));
+    if (Mcfg > M) { M = Mcfg; }
+    m->capB = (int)M; m->capT = 1;
+    const int E = m->E, L = m->L;
+    const size_t es = m->es;
+    m->xs.resize(L + 1);
+    for (int i = 0; i <= L; i++) CHECK_RC(dev_alloc(m, &m->xs[i], (size_t)M * E * es));
+    m->act.resize(L);
+    const bool ln = m->cfg.use_layer_norm != 0;
+    for (int i = 0; i < L; i++) {
+        LayerAct& a = m->act[i];
+        if (ln) CHECK_RC(dev_alloc(m, &a.u, (size_t)M * E * es)); else a.u = m->xs[i];
+        CHECK_RC(dev_alloc(m, &a.qkv, (size_t)M * 3 * E * es));
+        CHECK_RC(dev_alloc(m, &a.att, (size_t)M * E * es));
+        CHECK_RC(dev_alloc(m, &a.r, (size_t)M * E * es));
+        if (ln) CHECK_RC(dev_alloc(m, &a.n, (size_t)M * E * es)); else a.n = a.r;
+        CHECK_RC(dev_alloc(m, &a.fc, (size_t)M * 4 * E * es));
+        CHECK_RC(dev_alloc(m, &a.g, (size_t)M * 4 * E * es));
+        CHECK_RC(dev_alloc(m, &a.ln1_mean, (size_t)M * 4));
+        CHECK_RC(dev_alloc(m, &a.ln1_rstd, (size_t)M * 4));
+        CHECK_RC(dev_alloc(m, &a.ln2_mean, (size_t)M * 4));
+        CHECK_RC(dev_alloc(m, &a.ln2_rstd, (size_t)M * 4));
+        CHECK_RC(dev_alloc(m, &a.lse, (size_t)M * m->H * 4));
+    }
+    CHECK_RC(dev_alloc(m, &m->hf, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->logits, (size_t)M * m->ldz * 4));
+    CHECK_RC(dev_alloc(m, &m->dlogits, (size_t)M * m->ldz * es));
+    CHECK_RC(dev_alloc(m, &m->lnf_mean, (size_t)M * 4));
+    CHECK_RC(dev_alloc(m, &m->lnf_rstd, (size_t)M * 4));
+    CHECK_RC(dev_alloc(m, &m->row_loss, (size_t)M * 4));
+    CHECK_RC(dev_alloc(m, &m->row_correct, (size_t)M * 4));
+    CHECK_RC(dev_alloc(m, &m->delta, (size_t)M * m->H * 4));
+    CHECK_RC(dev_alloc(m, &m->x_dev, (size_t)M * 4));
+    CHECK_RC(dev_alloc(m, &m->y_dev, (size_t)M * 4));
+    CHECK_RC(dev_alloc(m, &m->dx, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->dr, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->tmpE, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->dmask, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->dfc, (size_t)M * 4 * E * es));
+    CHECK_RC(dev_alloc(m, &m->dqkv, (size_t)M * 3 * E * es));
+    CHECK_RC(dev_alloc(m, &m->ln_ws, (size_t)cmp_k_layernorm_bwd_ws((int)std::min<int64_t>(M, 1 << 30), E)));
+    return CMP_OK;
+}
+
+// dropout of a gradient tensor (d(dropout(x)) = dy*mask/(1-p)); only launched when the rate is > 0
+template <typename T>
+__global__ void drop_apply_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n, DropCfg d) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = from_f32<T>(apply_drop(d, (uint64_t)i, to_f32<T>(in[i])));
+}
+static int drop_apply(cmp_model* m, const void* in, void* out, int64_t n, float p, uint32_t stream_id) {
+    DropCfg d = make_drop(p, m->cfg.seed, stream_id);
+    int grid = (int)std::min<int64_t>(cdiv64(n, 256), 8192);
+    if (m->dtype == CMP_BF16)
+        drop_apply_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)in, (bf16_t*)out, n, d);
+    else
+        drop_apply_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)in, (float*)out, n, d);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward: Transformer.call (transformer.py:696-833) with past=None
+// -------------------------------------------------------------------------------------------------
+static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
+                int splitk, float p_drop, uint32_t rng_stream) {
+    return cmp_k_gemm(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
+                      out_fp32, splitk, p_drop, m->cfg.seed, rng_stream);
+}
+
+int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step) {
+    hipStream_t s = m->ctx->stream;
+    const int E = m->E, M = B * T, dt = m->dtype;
+    const float pr = training ? m->cfg.resid_dropout : 0.f;
+    const float pa = training ? m->cfg.attn_dropout : 0.f;
+    const bool ln = m->cfg.use_layer_norm != 0;
+    CHECK_RC(cmp_k_embed_fwd(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, 0, dt, pr, m->cfg.seed,
+                             drop_stream(step, 0, 0)));
+    for (int i = 0; i < m->L; i++) {
+        const LayerOff& o = m->lo[i];
+        LayerAct& a = m->act[i];
+        if (ln)   // transformer.py:583-584 -- the LN output REPLACES the residual stream
+            CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[i], m->P + o.ln1_g, m->P + o.ln1_b, a.u, a.ln1_mean, a.ln1_rstd, M, E,
+                                         m->cfg.ln_eps, dt));
+        CHECK_RC(gemm(m, 0, 0, M, 3 * E, E, a.u, E, m->w(o.attn_w), 3 * E, a.qkv, 3 * E, m->P + o.attn_b, 0, nullptr, 0,
+                      nullptr, 0, 0, 1, 0.f, 0));
+        CHECK_RC(cmp_k_attn_fwd(s, a.qkv, a.att, a.lse, B, T, m->H, m->D, m->cfg.scale_attention, dt, pa, m->cfg.seed,
+                                drop_stream(step, i, 1)));
+        CHECK_RC(gemm(m, 0, 0, M, E, E, a.att, E, m->w(o.proj_w), E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
+                      drop_stream(step, i, 2)));                                   // r = u + dropout(proj)  :587
+        if (ln)
+            CHECK_RC(cmp_k_layernorm_fwd(s, a.r, m->P + o.ln2_g, m->P + o.ln2_b, a.n, a.ln2_mean, a.ln2_rstd, M, E,
+                                         m->cfg.ln_eps, dt));
+        CHECK_RC(gemm(m, 0, 0, M, 4 * E, E, a.n, E, m->w(o.fc_w), 4 * E, a.g, 4 * E, m->P + o.fc_b, 1, a.fc, 4 * E, nullptr, 0,
+                      0, 1, 0.f, 0));                                              // g = gelu(fc)           :504
+        CHECK_RC(gemm(m, 0, 0, M, E, 4 * E, a.g, 4 * E, m->w(o.pr_w), E, m->xs[i + 1], E, m->P + o.pr_b, 0, nullptr, 0, a.r, E,
+                      0, 1, pr, drop_stream(step, i, 3)));                         // x = r + dropout(mlp)   :594
+    }
+    CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[m->L], m->P + m->off_lnf_g, m->P + m->off_lnf_b, m->hf, m->lnf_mean, m->lnf_rstd, M,
+                                 E, m->cfg.ln_eps, dt));                           // :811 (always applied)
+    CHECK_RC(gemm(m, 0, 1, M, m->V, E, m->hf, E, m->w(m->off_wte), E, m->logits, m->ldz, nullptr, 0, nullptr, 0, nullptr, 0, 1,
+                  1, 0.f, 0));                                                     // tied logits            :818
+    return CMP_OK;
+}
+
+static int loss(cmp_model* m, const int32_t* y_dev, int M, bool want_grad) {
+    hipStream_t s = m->ctx->stream;
+    CHECK_RC(cmp_k_softmax_xent(s, m->logits, m->ldz, y_dev, want_grad ? m->dlogits : nullptr, m->row_loss, m->row_correct, M,
+                                m->V, 1.0f / (float)M, m->dtype));
+    CHECK_RC(launch_metrics_reduce(s, m->row_loss, m->row_correct, M, m->metrics));
+    return CMP_OK;
+}
+
+static int wgrad_splits(int K, int M, int N) {
+    // contraction over tokens: make ~512+ workgroups
+    int tiles = cdiv(M, 128) * cdiv(N, 128);
+    int s = std::max(1, 768 / std::max(1, tiles));
+    return std::min(s, std::max(1, K / 256));
+}
+
+static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end) {
+    cmp_ctx* c = m->ctx;
+    if (c->nranks <= 1 || !c->comm) return CMP_OK;
+    HIP_CHECK(hipEventRecord(m->bucket_ev[ev], c->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->comm_stream, m->bucket_ev[ev], 0));
+    NCCL_CHECK(ncclAllReduce(m->G + begin, m->G + begin, (size_t)(end - begin), ncclFloat, ncclSum, c->comm, c->comm_stream));
+    return CMP_OK;
+}
+
+// reverse mode of forward() (tf.GradientTape, transformer.py:916-920); formulas in SURVEY appendix A
+static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t step, bool allreduce) {
+    hipStream_t s = m->ctx->stream;
+    const int E = m->E, M = B * T, dt = m->dtype, V = m->V;
+    const float pr = m->cfg.resid_dropout, pa = m->cfg.attn_dropout;
+    const bool ln = m->cfg.use_layer_norm != 0;
+    HIP_CHECK(hipMemsetAsync(m->G, 0, (size_t)m->total * 4, s));
+    // tied logits: dwte += dZ^T.hf ; dhf = dZ.wte
+    CHECK_RC(gemm(m, 1, 0, V, E, M, m->dlogits, m->ldz, m->hf, E, m->G + m->off_wte, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
+                  std::max(2, wgrad_splits(M, V, E)), 0.f, 0));
+    CHECK_RC(gemm(m, 0, 0, M, E, V, m->dlogits, m->ldz, m->w(m->off_wte), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0,
+                  1, 0.f, 0));
+    CHECK_RC(cmp_k_layernorm_bwd(s, m->tmpE, m->xs[m->L], m->P + m->off_lnf_g, m->lnf_mean, m->lnf_rstd, nullptr, m->dx,
+                                 m->G + m->off_lnf_g, m->G + m->off_lnf_b, m->ln_ws, M, E, dt));
+    if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total));
+    for (int i = m->L - 1; i >= 0; i--) {
+        const LayerOff& o = m->lo[i];
+        LayerAct& a = m->act[i];
+        // ---- MLP: x_out = r + dropout(gelu(n.Wfc+b).Wpr+b)
+        const void* dmo = m->dx;
+        if (pr > 0.f) {
+            CHECK_RC(drop_apply(m, m->dx, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 3)));
+            dmo = m->dmask;
+        }
+        CHECK_RC(gemm(m, 1, 0, 4 * E, E, M, a.g, 4 * E, dmo, E, m->G + o.pr_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
+                      std::max(2, wgrad_splits(M, 4 * E, E)), 0.f, 0));
+        CHECK_RC(cmp_k_colsum(s, dmo, E, m->G + o.pr_b, M, E, dt));
+        CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, dmo, E, m->w(o.pr_w), E, m->dfc, 4 * E, nullptr, 2, a.fc, 4 * E, nullptr, 0, 0, 1,
+                      0.f, 0));                                                    // dfc = (dmo.Wpr^T) * gelu'(fc)
+        CHECK_RC(gemm(m, 1, 0, E, 4 * E, M, a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
+                      std::max(2, wgrad_splits(M, E, 4 * E)), 0.f, 0));
+        CHECK_RC(cmp_k_colsum(s, m->dfc, 4 * E, m->G + o.fc_b, M, 4 * E, dt));
+        if (ln) {
+            CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr,
+                          0, 0, 1, 0.f, 0));                                       // dn
+            CHECK_RC(cmp_k_layernorm_bwd(s, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr,
+                                         m->G + o.ln2_g, m->G + o.ln2_b, m->ln_ws, M, E, dt));   // dr = dx + LN2'(dn)
+        } else {
+            CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->dr, E, nullptr, 0, nullptr, 0, m->dx, E,
+                          0, 1, 0.f, 0));                                          // dr = dx + dn
+        }
+        // ---- attention: r = u + dropout(att.Wproj+b)
+        const void* dao = m->dr;
+        if (pr > 0.f) {
+            CHECK_RC(drop_apply(m, m->dr, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 2)));
+            dao = m->dmask;
+        }
+        CHECK_RC(gemm(m, 1, 0, E, E, M, a.att, E, dao, E, m->G + o.proj_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
+                      std::max(2, wgrad_splits(M, E, E)), 0.f, 0));
+        CHECK_RC(cmp_k_colsum(s, dao, E, m->G + o.proj_b, M, E, dt));
+        CHECK_RC(gemm(m, 0, 1, M, E, E, dao, E, m->w(o.proj_w), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
+                      0));                                                         // datt
+        CHECK_RC(cmp_k_attn_bwd(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
+                                dt, pa, m->cfg.seed, drop_stream(step, i, 1)));
+        CHECK_RC(gemm(m, 1, 0, E, 3 * E, M, a.u, E, m->dqkv, 3 * E, m->G + o.attn_w, 3 * E, nullptr, 0, nullptr, 0, nullptr, 0,
+                      1, std::max(2, wgrad_splits(M, E, 3 * E)), 0.f, 0));
+        CHECK_RC(cmp_k_colsum(s, m->dqkv, 3 * E, m->G + o.attn_b, M, 3 * E, dt));
+        if (ln) {
+            CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
+                          E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T
+            CHECK_RC(cmp_k_layernorm_bwd(s, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx,
+                                         m->G + o.ln1_g, m->G + o.ln1_b, m->ln_ws, M, E, dt));   // dx_in = LN1'(du): no skip
+        } else {
+            CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->dx, E, nullptr, 0, nullptr, 0, m->dr, E,
+                          0, 1, 0.f, 0));
+        }
+        if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end));
+    }
+    CHECK_RC(cmp_k_embed_bwd(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->cfg.seed,
+                             drop_stream(step, 0, 0)));
+    if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin));
+    return CMP_OK;
+}
+
+static int adam(cmp_model* m, float lr) {
+    cmp_ctx* c = m->ctx;
+    float gscale = 1.0f;
+    if (c->nranks > 1 && c->comm) {
+        HIP_CHECK(hipEventRecord(m->comm_done, c->comm_stream));
+        HIP_CHECK(hipStreamWaitEvent(c->stream, m->comm_done, 0));
+        gscale = 1.0f / (float)c->nranks;       // all-reduce summed: global-batch mean gradient
+    }
+    m->iterations += 1;
+    return cmp_k_adam(c->stream, m->P, m->G, m->Am, m->Av, m->S, m->total, lr, 0.9f, 0.999f, 1e-7f, m->iterations, gscale);
+}
+
+static int fetch_metrics(cmp_model* m) {
+    HIP_CHECK(hipMemcpyAsync(m->metrics_host, m->metrics, sizeof(Metrics), hipMemcpyDeviceToHost, m->ctx->stream));
+    return CMP_OK;
+}
+
+extern "C" int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, float lr) {
+    CMP_REQUIRE(m && x_dev && y_dev, "train_step_dev: null argument");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(ensure_workspace(m, B, T));
+    const int64_t step = m->iterations;
+    CHECK_RC(model_forward(m, (const int32_t*)x_dev, B, T, true, step));
+    CHECK_RC(loss(m, (const int32_t*)y_dev, B * T, true));
+    CHECK_RC(backward(m, (const int32_t*)x_dev, B, T, step, true));
+    CHECK_RC(adam(m, lr));
+    CHECK_RC(fetch_metrics(m));
+    return CMP_OK;
+}
+
+extern "C" int cmp_train_metrics(cmp_model* m, float* loss_out, float* acc_out) {
+    CMP_REQUIRE(m, "train_metrics: null model");
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    if (loss_out) *loss_out = m->metrics_host->loss_mean;
+    if (acc_out) *acc_out = m->metrics_host->acc;
+    return CMP_OK;
+}
+
+static int upload_xy(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T) {
+    CHECK_RC(ensure_workspace(m, B, T));
+    HIP_CHECK(hipMemcpyAsync(m->x_dev, x, (size_t)B * T * 4, hipMemcpyHostToDevice, m->ctx->stream));
+    if (y) HIP_CHECK(hipMemcpyAsync(m->y_dev, y, (size_t)B * T * 4, hipMemcpyHostToDevice, m->ctx->stream));
+    return CMP_OK;
+}
+
+extern "C" int cmp_train_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, float lr, float* loss_out,
+                              float* acc_out) {
+    CMP_REQUIRE(m && x && y, "train_step: null argument");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(upload_xy(m, x, y, B, T));
+    CHECK_RC(cmp_train_step_dev(m, m->x_dev, m->y_dev, B, T, lr));
+    if (loss_out || acc_out) CHECK_RC(cmp_train_metrics(m, loss_out, acc_out));
+    return CMP_OK;
+}
+
+extern "C" int cmp_loss_and_grads(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, float* loss_out,
+                                  float* acc_out) {
+    CMP_REQUIRE(m && x && y, "loss_and_grads: null argument");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(upload_xy(m, x, y, B, T));
+    const int64_t step = m->iterations;
+    CHECK_RC(model_forward(m, m->x_dev, B, T, true, step));
+    CHECK_RC(loss(m, m->y_dev, B * T, true));
+    CHECK_RC(backward(m, m->x_dev, B, T, step, false));
+    CHECK_RC(fetch_metrics(m));
+    CHECK_RC(cmp_train_metrics(m, loss_out, acc_out));
+    return CMP_OK;
+}
+
+extern "C" int cmp_eval_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, double* loss_sum,
+                             int64_t* correct, int64_t* count) {
+    CMP_REQUIRE(m && x && y, "eval_step: null argument");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(upload_xy(m, x, y, B, T));
+    CHECK_RC(model_forward(m, m->x_dev, B, T, false, 0));
+    CHECK_RC(loss(m, m->y_dev, B * T, false));
+    CHECK_RC(fetch_metrics(m));
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    if (loss_sum) *loss_sum = m->metrics_host->loss_sum;
+    if (correct) *correct = m->metrics_host->correct;
+    if (count) *count = (int64_t)B * T;
+    return CMP_OK;
+}
+
+extern "C" int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logits_out) {
+    CMP_REQUIRE(m && x && logits_out, "forward_logits: null argument");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(upload_xy(m, x, nullptr, B, T));
+    CHECK_RC(model_forward(m, m->x_dev, B, T, false, 0));
+    HIP_CHECK(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->ldz * 4, (size_t)m->V * 4, (size_t)B * T,
+                               hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    return CMP_OK;
+}

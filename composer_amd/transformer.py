@@ -1,0 +1,410 @@
+"""Host-side mirror of the reference's `composer.models.Transformer` (reference
+composer/models/transformer.py:599-960) over libcomposer_hip.so.
+
+Same constructor arguments (transformer.py:610-614), same call / train / evaluate / load_from_checkpoint
+surface (cli.py:579-589, 606-615, 635-676).  All arithmetic happens in hand-written HIP kernels on an
+MI355X; this file only moves integers in and numbers out.  There is no CPU path.
+"""
+import ctypes as C
+import enum
+import logging
+import math
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from . import checkpoint as ckpt
+
+
+class ModelSaveFrequencyMode(enum.Enum):
+    """reference composer/models/__init__.py:92-107"""
+    EPOCH = 'epoch'
+    GLOBAL_STEP = 'global_step'
+
+
+def _truncated_normal(rng, shape, mean, stddev):
+    """tf.keras.initializers.TruncatedNormal: resample outside +-2 sigma (transformer.py:115,188,670-673)."""
+    a = rng.standard_normal(shape)
+    bad = np.abs(a) > 2.0
+    while bad.any():
+        a[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(a) > 2.0
+    return (mean + stddev * a).astype(np.float32)
+
+
+class Presents:
+    """Lazy `presents` tuple (transformer.py:797-806,820-821): L tensors [2,B,H,T,D] fetched from the saved
+    c_attn activations only when indexed (the CLI never reads them)."""
+
+    def __init__(self, model, B, T):
+        self._m, self._B, self._T = model, B, T
+
+    def __len__(self):
+        return self._m.decoder_layers_count
+
+    def __getitem__(self, i):
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._m._fetch_present(i, self._B, self._T)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class Transformer:
+    def __init__(self, vocab_size, embedding_size, window_size, decoder_layers_count,
+                 attention_head_count, use_relative_attention=False, initializer_mean=0,
+                 initializer_stddev=0.02, attention_dropout_rate=0.1, residual_dropout_rate=0.1,
+                 layer_normalization_epsilon=1e-5, scale=True, use_layer_normalization=True,
+                 output_hidden_states=False, output_attention_weights=False, *,
+                 dtype='bf16', seed=0, max_batch=1, max_seq=None, device=None, ctx=None):
+        if embedding_size % attention_head_count != 0:
+            raise AssertionError('hidden size must be a multiple of the attention head count')   # transformer.py:255
+        if use_relative_attention:
+            # the reference path is broken (Attention.build reads an undefined self.depth, transformer.py:285)
+            raise NotImplementedError('use_relative_attention is not supported (broken in the reference too)')
+        if output_hidden_states or output_attention_weights:
+            raise NotImplementedError('output_hidden_states / output_attention_weights are never used by the CLI path')
+        self.vocab_size = vocab_size
+        self.embedding_size = embedding_size
+        self.window_size = window_size
+        self.decoder_layers_count = decoder_layers_count
+        self.attention_head_count = attention_head_count
+        self.use_layer_normalization = use_layer_normalization
+        self.initializer_mean = initializer_mean
+        self.initializer_stddev = initializer_stddev
+        self.dtype = {'fp32': _lib.CMP_FP32, 'float32': _lib.CMP_FP32, 'bf16': _lib.CMP_BF16,
+                      'bfloat16': _lib.CMP_BF16}[str(dtype)]
+        self.seed = int(seed)
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+        self._own_ctx = ctx is None
+        if ctx is None:
+            h = C.c_void_p()
+            _lib.check(self._lib.cmp_ctx_create(int(device), C.byref(h)), 'cmp_ctx_create')
+            ctx = h
+        self._ctx = ctx
+        cfg = _lib.ModelCfg(vocab_size, embedding_size, window_size, decoder_layers_count, attention_head_count,
+                            float(layer_normalization_epsilon), int(bool(scale)), int(bool(use_layer_normalization)),
+                            float(attention_dropout_rate), float(residual_dropout_rate), self.dtype,
+                            int(max_batch), int(max_seq or window_size), self.seed)
+        h = C.c_void_p()
+        _lib.check(self._lib.cmp_model_create(self._ctx, C.byref(cfg), C.byref(h)), 'cmp_model_create')
+        self._h = h
+        self._specs = self._param_specs()
+        self._learning_rate = 1e-3
+        self._dp = None          # (rank, nranks) once init_data_parallel() ran
+        self.initialize_parameters(self.seed)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.cmp_model_destroy(self._h)
+            self._h = None
+            if self._own_ctx and self._ctx:
+                self._lib.cmp_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def _param_specs(self):
+        n = C.c_int()
+        _lib.check(self._lib.cmp_param_count(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            name, rank, shape, numel = C.c_char_p(), C.c_int(), (C.c_int64 * 4)(), C.c_int64()
+            _lib.check(self._lib.cmp_param_info(self._h, i, C.byref(name), C.byref(rank), C.byref(shape), C.byref(numel)))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(rank.value)), int(numel.value)))
+        return out
+
+    @property
+    def parameter_names(self):
+        return [n for n, _, _ in self._specs]
+
+    def parameter_shape(self, name):
+        return {n: s for n, s, _ in self._specs}[name]
+
+    def get_parameter(self, name, kind=_lib.KIND_VALUE):
+        shape = self.parameter_shape(name)
+        a = np.empty(shape, np.float32)
+        _lib.check(self._lib.cmp_param_get(self._h, name.encode(), kind, a.ctypes.data_as(C.c_void_p), a.size), 'cmp_param_get')
+        return a
+
+    def set_parameter(self, name, value, kind=_lib.KIND_VALUE):
+        a = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(self.parameter_shape(name)))
+        _lib.check(self._lib.cmp_param_set(self._h, name.encode(), kind, a.ctypes.data_as(C.c_void_p), a.size), 'cmp_param_set')
+
+    def get_weights(self):
+        return {n: self.get_parameter(n) for n in self.parameter_names}
+
+    def set_weights(self, weights):
+        for n, v in weights.items():
+            self.set_parameter(n, v)
+
+    def initialize_parameters(self, seed=0):
+        """TruncatedNormal(mean, stddev) for wte/wpe/Conv1D weights, zeros for biases/beta, ones for gamma
+        (transformer.py:115,188-190,670-673; Keras LayerNormalization defaults)."""
+        rng = np.random.default_rng(seed)
+        for name, shape, _ in self._specs:
+            if name.endswith('gamma'):
+                v = np.ones(shape, np.float32)
+            elif name.endswith(('beta', 'bias')):
+                v = np.zeros(shape, np.float32)
+            else:
+                v = _truncated_normal(rng, shape, self.initializer_mean, self.initializer_stddev)
+            self.set_parameter(name, v)
+
+    @property
+    def iterations(self):
+        v = C.c_int64()
+        _lib.check(self._lib.cmp_adam_iter_get(self._h, C.byref(v)))
+        return int(v.value)
+
+    @iterations.setter
+    def iterations(self, v):
+        _lib.check(self._lib.cmp_adam_iter_set(self._h, int(v)))
+
+    # ------------------------------------------------------------------ Keras-surface no-ops used by the CLI
+    def compile(self, learning_rate):            # transformer.py:835-844
+        self._learning_rate = float(learning_rate)
+
+    def build(self, input_shape=None):           # cli.py:607,640
+        return None
+
+    def reset_states(self):                      # cli.py:662
+        return None
+
+    def summary(self, print_fn=print):           # cli.py:436-440
+        total = 0
+        print_fn('Model: "transformer"')
+        for n, s, k in self._specs:
+            print_fn('%-48s %-16s %d' % (n, s, k))
+            total += k
+        print_fn('Total params: {:,}'.format(total))
+        return total
+
+    # ------------------------------------------------------------------ data parallel
+    def init_data_parallel(self, rank, world_size, unique_id):
+        """One rank per GPU; `unique_id` = 128 bytes from rank 0's `new_unique_id()` shared by the launcher."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self._lib.cmp_dp_init(self._ctx, int(rank), int(world_size), buf), 'cmp_dp_init')
+        self._dp = (int(rank), int(world_size))
+
+    @staticmethod
+    def new_unique_id():
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().cmp_dp_unique_id(buf), 'cmp_dp_unique_id')
+        return buf.raw
+
+    # ------------------------------------------------------------------ forward / steps
+    @staticmethod
+    def _ids(x):
+        a = np.ascontiguousarray(np.asarray(x).astype(np.int32))
+        if a.ndim == 1:
+            a = a[None]
+        if a.ndim != 2:
+            raise ValueError('expected an int tensor with shape [batch, sequence]')
+        return a
+
+    def _check_ids(self, a):
+        if a.size and (a.min() < 0 or a.max() >= self.vocab_size):
+            raise ValueError('token id outside [0, %d)' % self.vocab_size)
+
+    def __call__(self, inputs, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                 input_embeddings=None, use_cache=True, training=False):
+        """Transformer.call (transformer.py:696-833) -> (logits [B,T,V] float32, presents)."""
+        if past is not None:
+            raise NotImplementedError('host-supplied `past` is not supported; the KV cache lives on the device: '
+                                      'use generate(..., mode="kv")')
+        if attention_mask is not None or token_type_ids is not None or position_ids is not None or input_embeddings is not None:
+            raise NotImplementedError('attention_mask/token_type_ids/position_ids/input_embeddings are never used by the CLI path')
+        if training:
+            raise NotImplementedError('use train_step()/train() for training-mode passes')
+        x = self._ids(inputs)
+        self._check_ids(x)
+        B, T = x.shape
+        logits = np.empty((B, T, self.vocab_size), np.float32)
+        _lib.check(self._lib.cmp_forward_logits(self._h, x.ctypes.data_as(C.c_void_p), B, T,
+                                                logits.ctypes.data_as(C.c_void_p)), 'cmp_forward_logits')
+        if use_cache is True:
+            return logits, Presents(self, B, T)
+        return (logits,)
+
+    def _fetch_present(self, layer, B, T):
+        raise NotImplementedError('presents are kept on the device (KV cache); not exported in this build')
+
+    def train_step(self, x, y, learning_rate=None, sync=True):
+        """One iteration of transformer.py:914-930: returns (loss, accuracy) of this rank's batch."""
+        x, y = self._ids(x), self._ids(y)
+        self._check_ids(x); self._check_ids(y)
+        B, T = x.shape
+        lr = self._learning_rate if learning_rate is None else float(learning_rate)
+        loss, acc = C.c_float(), C.c_float()
+        _lib.check(self._lib.cmp_train_step(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), B, T, lr,
+                                            C.byref(loss) if sync else None, C.byref(acc) if sync else None), 'cmp_train_step')
+        return (loss.value, acc.value) if sync else None
+
+    def train_step_device(self, x_ptr, y_ptr, B, T, learning_rate=None):
+        """x_ptr / y_ptr: HIP device pointers to int32 [B,T] (e.g. torch tensor .data_ptr()); no host sync."""
+        lr = self._learning_rate if learning_rate is None else float(learning_rate)
+        _lib.check(self._lib.cmp_train_step_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), B, T, lr), 'cmp_train_step_dev')
+
+    def last_metrics(self):
+        loss, acc = C.c_float(), C.c_float()
+        _lib.check(self._lib.cmp_train_metrics(self._h, C.byref(loss), C.byref(acc)), 'cmp_train_metrics')
+        return loss.value, acc.value
+
+    def synchronize(self):
+        _lib.check(self._lib.cmp_sync(self._ctx), 'cmp_sync')
+
+    @property
+    def stream(self):
+        return self._lib.cmp_ctx_stream(self._ctx)
+
+    def loss_and_grads(self, x, y):
+        """forward(training=True)+backward without the optimizer; gradients via get_parameter(name, KIND_GRAD)."""
+        x, y = self._ids(x), self._ids(y)
+        B, T = x.shape
+        loss, acc = C.c_float(), C.c_float()
+        _lib.check(self._lib.cmp_loss_and_grads(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), B, T,
+                                                C.byref(loss), C.byref(acc)), 'cmp_loss_and_grads')
+        return loss.value, acc.value
+
+    def evaluate(self, dataset, verbose=0):
+        """model.evaluate(ds) (cli.py:613): mean sparse-CE and token accuracy over all batches."""
+        tot, cor, cnt = 0.0, 0, 0
+        for x, y in dataset:
+            x, y = self._ids(x), self._ids(y)
+            B, T = x.shape
+            ls, c, n = C.c_double(), C.c_int64(), C.c_int64()
+            _lib.check(self._lib.cmp_eval_step(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), B, T,
+                                               C.byref(ls), C.byref(c), C.byref(n)), 'cmp_eval_step')
+            tot += ls.value; cor += c.value; cnt += n.value
+        if cnt == 0:
+            return float('nan'), float('nan')
+        return tot / cnt, cor / cnt
+
+    # ------------------------------------------------------------------ decode (cli.py:659-676)
+    def generate(self, prompt_ids, length, temperature=1.0, mode='kv', seed=None):
+        """Returns `length` generated ids.  mode 'literal' restates cli.py:663-676 as written (no `past`),
+        mode 'kv' is model(x, past=presents).  temperature <= 0 -> greedy argmax."""
+        p = np.ascontiguousarray(np.asarray(prompt_ids, dtype=np.int32).reshape(-1))
+        m = {'literal': _lib.DECODE_LITERAL, 'reference-literal': _lib.DECODE_LITERAL, 'kv': _lib.DECODE_KV,
+             'kv-cache': _lib.DECODE_KV}[mode]
+        if m == _lib.DECODE_KV and len(p) + length - 1 > self.window_size:
+            raise IndexError('prompt_len + length - 1 = %d exceeds window_size %d (wpe rows, transformer.py:675-679,786)'
+                             % (len(p) + length - 1, self.window_size))
+        _lib.check(self._lib.cmp_decode_begin(self._h, p.ctypes.data_as(C.c_void_p), len(p), m, float(temperature),
+                                              int(self.seed if seed is None else seed)), 'cmp_decode_begin')
+        out = np.empty(length, np.int32)
+        _lib.check(self._lib.cmp_decode_steps(self._h, int(length), out.ctypes.data_as(C.c_void_p)), 'cmp_decode_steps')
+        return out
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        sd = {}
+        for n in self.parameter_names:
+            sd['model/' + n] = self.get_parameter(n)
+            sd['optimizer/m/' + n] = self.get_parameter(n, _lib.KIND_ADAM_M)
+            sd['optimizer/v/' + n] = self.get_parameter(n, _lib.KIND_ADAM_V)
+        sd['optimizer/iter'] = np.int64(self.iterations)
+        return sd
+
+    def load_state_dict(self, sd, expect_partial=False):
+        for n in self.parameter_names:
+            self.set_parameter(n, sd['model/' + n])
+            if 'optimizer/m/' + n in sd:
+                self.set_parameter(n, sd['optimizer/m/' + n], _lib.KIND_ADAM_M)
+                self.set_parameter(n, sd['optimizer/v/' + n], _lib.KIND_ADAM_V)
+            elif not expect_partial:
+                raise KeyError('optimizer slot for ' + n)
+        if 'optimizer/iter' in sd:
+            self.iterations = int(sd['optimizer/iter'])
+
+    def load_from_checkpoint(self, restoredir):
+        """BaseModel.load_from_checkpoint (reference composer/models/__init__.py:66-90): restores the latest
+        checkpoint in `restoredir` (model only, expect_partial); logs and exits(1) on failure."""
+        try:
+            mgr = ckpt.CheckpointManager(restoredir, max_to_keep=None)
+            if mgr.latest_checkpoint is None:
+                raise FileNotFoundError('no checkpoint in ' + str(restoredir))
+            sd, _meta = ckpt.load(mgr.latest_checkpoint)
+            self.load_state_dict(sd, expect_partial=True)
+            logging.info('Model restored from \'{}\'.'.format(mgr.latest_checkpoint))
+        except Exception:
+            logging.error('Failed to restore model from \'{}\'.'.format(restoredir))
+            exit(1)
+
+    # ------------------------------------------------------------------ train loop (transformer.py:846-960)
+    def train(self, dataset, input_shape, logdir, restoredir=None, epochs=None, learning_rate=1e-3,
+              save_frequency_mode=ModelSaveFrequencyMode.EPOCH, save_frequency=1, max_checkpoints=1,
+              show_progress_bar=True, max_steps=None):
+        logdir = Path(logdir) if logdir is not None else None
+        if restoredir is not None:
+            logdir = Path(restoredir)                                            # :884-885
+        rank = self._dp[0] if self._dp else 0
+        manager = ckpt.CheckpointManager(logdir, max_to_keep=max_checkpoints)   # :890-891
+        step, epoch = 1, 1
+        if restoredir is not None:                                               # :894-900
+            try:
+                sd, meta = ckpt.load(manager.latest_checkpoint)
+                self.load_state_dict(sd)
+                step, epoch = int(meta['step']), int(meta['epoch'])
+                logging.info('Model restored from \'{}\'.'.format(manager.latest_checkpoint))
+            except Exception:
+                logging.error('Failed to restore model from \'{}\'.'.format(restoredir))
+                exit(1)
+        summary = ckpt.ScalarLog(logdir / 'train') if rank == 0 else None        # :903
+        save_frequency_mode = ModelSaveFrequencyMode(save_frequency_mode)
+        history = []
+
+        def save():
+            if rank != 0:
+                return None
+            return manager.save(self.state_dict(), {'step': step, 'epoch': epoch})
+
+        done = False
+        while (epochs is None or epoch < epochs) and not done:                   # :907 (epoch starts at 1)
+            logging.info('Epoch {}'.format(epoch if epochs is None else '{}/{}'.format(epoch, epochs)))
+            ep_loss, ep_correct, ep_n, t0 = 0.0, 0.0, 0, time.time()
+            for x, y in dataset:                                                 # :914
+                loss, acc = self.train_step(x, y, learning_rate)
+                ep_loss += loss; ep_correct += acc; ep_n += 1
+                history.append((step, loss, acc))
+                if summary:
+                    summary.scalar('loss', loss, step)                           # :933-936
+                    summary.scalar('accuracy', acc, step)
+                if show_progress_bar and rank == 0 and (ep_n % 10 == 1):
+                    print('\r- loss: {:.4f} - accuracy: {:.4f}'.format(loss, acc), end='', flush=True)   # :939
+                if save_frequency_mode == ModelSaveFrequencyMode.GLOBAL_STEP and step % save_frequency == 0:
+                    path = save()                                                # :941-943
+                    if path and show_progress_bar:
+                        print('\nSaved checkpoint for step {} at {}.'.format(step, path))
+                step += 1                                                        # :945
+                if max_steps is not None and len(history) >= max_steps:
+                    done = True
+                    break
+            if ep_n == 0:
+                logging.error('The dataset yielded no batches.')
+                break
+            if summary:
+                summary.scalar('epoch_loss', ep_loss / ep_n, epoch)              # :949-951
+                summary.scalar('epoch_accuracy', ep_correct / ep_n, epoch)
+            if save_frequency_mode == ModelSaveFrequencyMode.EPOCH and epoch % save_frequency == 0:
+                path = save()                                                    # :953-955
+                if path and show_progress_bar:
+                    print('\nSaved checkpoint for epoch {} at {}.'.format(epoch, path))
+            epoch += 1                                                           # :960
+        if summary:
+            summary.close()
+        return history

@@ -1,0 +1,163 @@
+/*
+ * composer_hip.h -- C ABI of libcomposer_hip.so: the MI355X (gfx950) implementation of
+ * galacticglum/composer's Transformer hot path (teacher-forced train step, evaluation step,
+ * autoregressive decode).
+ *
+ * The reference has no FFI: its seam is the Python class `composer.models.Transformer`
+ * (reference composer/models/transformer.py:599-960) called from composer/cli.py:95-141,516-680.
+ * Each entry point below names the reference interface it replaces.  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success, a negative cmp_status otherwise;
+ * cmp_last_error() returns a thread-local, library-owned message for the last failure.
+ * Plain pointers and sizes only.  "host" pointers are ordinary CPU memory owned by the caller for
+ * the duration of the call; "dev" pointers are HIP device pointers (the cmp_k_* kernel-level entry
+ * points, used by the parity tests and micro-benchmarks, take dev pointers and a hipStream_t passed
+ * as void*).  A cmp_ctx is bound to one device and is not thread-safe.
+ */
+#ifndef COMPOSER_HIP_H
+#define COMPOSER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmp_ctx cmp_ctx;
+typedef struct cmp_model cmp_model;
+
+enum cmp_status {
+    CMP_OK = 0,
+    CMP_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    CMP_ERR_HIP = -2,       /* a HIP runtime call failed */
+    CMP_ERR_RCCL = -3,      /* an RCCL call failed */
+    CMP_ERR_STATE = -4      /* call sequence error (e.g. decode_steps before decode_begin) */
+};
+
+enum cmp_dtype {
+    CMP_FP32 = 0,           /* fp32 storage + f32-input MFMA: the parity mode */
+    CMP_BF16 = 1            /* bf16 activations / weight shadow, fp32 accumulate + master: throughput */
+};
+
+enum cmp_decode_mode {
+    CMP_DECODE_LITERAL = 0, /* composer/cli.py:663-676 as written: `past` never fed back */
+    CMP_DECODE_KV = 1       /* model(x, past=presents), transformer.py:735-765,423-426 */
+};
+
+/* Constructor arguments of Transformer.__init__ (transformer.py:610-614) plus device-side sizing. */
+typedef struct cmp_model_cfg {
+    int32_t vocab_size;        /* V  */
+    int32_t embedding_size;    /* E, multiple of 8 */
+    int32_t window_size;       /* W = rows of wpe */
+    int32_t layers;            /* L  */
+    int32_t heads;             /* H, E % H == 0 (transformer.py:255), E/H in {16,32,64,128} */
+    float   ln_eps;            /* layer_normalization_epsilon */
+    int32_t scale_attention;   /* `scale` */
+    int32_t use_layer_norm;    /* `use_layer_normalization` */
+    float   attn_dropout;      /* attention_dropout_rate */
+    float   resid_dropout;     /* residual_dropout_rate */
+    int32_t dtype;             /* cmp_dtype */
+    int32_t max_batch;         /* largest B of any later call */
+    int32_t max_seq;           /* largest T of any later call (<= window_size) */
+    uint64_t seed;             /* dropout / sampling seed */
+} cmp_model_cfg;
+
+const char* cmp_last_error(void);
+int cmp_version(void);
+/* number of visible HIP devices (0 when none); never initialises a device context beyond the count */
+int cmp_device_count(void);
+
+/* ---- context: one per (process, device) ------------------------------------------------------ */
+int cmp_ctx_create(int device, cmp_ctx** out);
+int cmp_ctx_destroy(cmp_ctx* ctx);
+int cmp_sync(cmp_ctx* ctx);
+/* hipStream_t of the compute stream (for HIP-event timing by the caller) */
+void* cmp_ctx_stream(cmp_ctx* ctx);
+
+/* ---- data parallel: RCCL communicator, one rank per process (new; the reference is single-device) */
+int cmp_dp_unique_id(void* id128);                                   /* rank 0: fills 128 bytes */
+int cmp_dp_init(cmp_ctx* ctx, int rank, int nranks, const void* id128);
+int cmp_dp_allreduce_test(cmp_ctx* ctx, float* host_inout, int n);    /* sum over ranks, for tests */
+
+/* ---- model: replaces models.Transformer(...) construction (cli.py:123-132) --------------------- */
+int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_model** out);
+int cmp_model_destroy(cmp_model* m);
+
+/* parameter / optimizer-state surface == checkpoint surface (transformer.py:890, models/__init__.py:75-80).
+ * Names: "wte/weight" [V,E], "wpe/embeddings" [W,E], "decoder_blocks/<i>/{ln_1,ln_2}/{gamma,beta}" [E],
+ * ".../attn/{c_attn,c_proj}/{weight,bias}", ".../mlp/{c_fc,c_proj}/{weight,bias}" (bias is [1,N],
+ * transformer.py:190), "ln_f/{gamma,beta}".  kind: 0 value, 1 Adam m, 2 Adam v, 3 last gradient. */
+int cmp_param_count(cmp_model* m, int* n);
+int cmp_param_info(cmp_model* m, int i, const char** name, int* rank, int64_t shape[4], int64_t* numel);
+int cmp_param_get(cmp_model* m, const char* name, int kind, float* host, int64_t numel);
+int cmp_param_set(cmp_model* m, const char* name, int kind, const float* host, int64_t numel);
+int cmp_adam_iter_get(cmp_model* m, int64_t* iterations);            /* Keras optimizer.iterations */
+int cmp_adam_iter_set(cmp_model* m, int64_t iterations);
+
+/* ---- training: one iteration of the loop body at transformer.py:914-930 ------------------------
+ * x, y: host int32 [B,T].  Forward (training=True) + sparse-CE + backward + (DP all-reduce) + Adam.
+ * loss/acc (host, may be NULL) are this rank's batch mean loss and accuracy. */
+int cmp_train_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, float lr,
+                   float* loss, float* acc);
+/* Device-resident variant: x_dev/y_dev int32 [B,T] already in HBM; loss/acc are fetched later with
+ * cmp_train_metrics (no host sync in the step itself). */
+int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, float lr);
+int cmp_train_metrics(cmp_model* m, float* loss, float* acc);        /* syncs; last step's values */
+/* forward+backward only (no all-reduce, no Adam): gradients readable with cmp_param_get(kind=3) */
+int cmp_loss_and_grads(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T,
+                       float* loss, float* acc);
+
+/* ---- evaluation: model.evaluate (cli.py:613) --------------------------------------------------- */
+int cmp_eval_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T,
+                  double* loss_sum, int64_t* correct, int64_t* count);
+
+/* ---- inference forward: Transformer.call(inputs, training=False) (transformer.py:696-833) -------
+ * logits_out: host fp32 [B,T,V]. */
+int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logits_out);
+
+/* ---- decode: the loop of cli.py:659-676 -------------------------------------------------------
+ * temperature <= 0 => argmax with lowest-index tie-break (the tau->0 limit; cli.py:671 divides). */
+int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int mode, float temperature, uint64_t seed);
+int cmp_decode_steps(cmp_model* m, int n, int32_t* ids_out);
+
+/* ---- kernel-level entry points (dev pointers; dtype = cmp_dtype of activations) ----------------
+ * Used by tests/ and bench.py to check and time single kernels against the oracle/roofline. */
+int cmp_k_embed_fwd(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out,
+                    int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream);
+int cmp_k_embed_bwd(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe,
+                    int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream);
+int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, int rows, int E, float eps, int dtype);
+/* dx = resid(optional) + LN_bwd(dy); dgamma/dbeta fp32 [E] are ACCUMULATED into; ws >= cmp_k_layernorm_bwd_ws bytes */
+int cmp_k_layernorm_bwd(void* stream, const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta,
+                        void* ws, int rows, int E, int dtype);
+int64_t cmp_k_layernorm_bwd_ws(int rows, int E);
+/* C[M,N] = epilogue(A.B): ta=0: A is [M,K] (lda); ta=1: A stored [K,M].  tb=0: B stored [K,N]; tb=1: B stored [N,K].
+ * epilogue: +bias[N] (fp32, may be NULL); act: 0 none, 1 gelu (pre-activation stored to aux if aux!=NULL),
+ * 2 multiply by gelu'(aux[m,n]); dropout (p>0) then +resid[m,n] (may be NULL).  out_fp32: C is fp32 regardless of
+ * dtype.  splitk>1: fp32 atomic accumulation into C (C must be pre-zeroed or hold the value to add to). */
+int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
+               const void* A, int lda, const void* Bm, int ldb, void* C, int ldc,
+               const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr,
+               int out_fp32, int splitk, float p_drop, uint64_t seed, uint32_t rng_stream);
+int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype);
+/* causal attention on qkv [B,T,3E] (head-merged, transformer.py:417): o [B,T,E], lse fp32 [B,H,T] */
+int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D,
+                   int scale, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream);
+int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
+                   float* delta_ws, void* dqkv, int B, int T, int H, int D, int scale, int dtype,
+                   float p_drop, uint64_t seed, uint32_t rng_stream);
+/* fused softmax cross-entropy forward+backward: logits fp32 [rows, ldz]; dlogits (dtype) [rows, ldz] with
+ * zeroed padding; row_loss fp32 [rows]; row_correct int32 [rows]; inv_n = 1/(B*T) */
+int cmp_k_softmax_xent(void* stream, const float* logits, int ldz, const int32_t* y, void* dlogits,
+                       float* row_loss, int32_t* row_correct, int rows, int V, float inv_n, int dtype);
+/* Keras Adam (transformer.py:887,921): eps outside the bias correction; step = optimizer.iterations+1 */
+int cmp_k_adam(void* stream, float* p, const float* g, float* m, float* v, void* shadow_bf16,
+               int64_t n, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMPOSER_HIP_H */

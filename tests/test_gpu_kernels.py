@@ -1,0 +1,312 @@
+"""-m gpu: kernel-level parity of the HIP kernels, called through the C ABI (cmp_k_*) with device memory
+borrowed from torch tensors.  References are float64 torch/numpy restatements of the same op (the oracle's
+formulas); the dropout tests use the oracle's counter hash so masks are bit-identical.
+
+Tolerances: fp32 mode ~1e-5 relative (f32 MFMA = exact fma chains, only summation order differs);
+bf16 mode: inputs are rounded to bf16 first, then the comparison allows the bf16 output rounding (2^-8 relative).
+"""
+import ctypes as C
+import math
+import numpy as np
+import pytest
+import torch
+
+from oracle import transformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP32, BF16 = 0, 1
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from composer_amd import _lib
+    l = _lib.load()
+    _lib.require_gpu()
+    return l
+
+
+def ck(lib, rc):
+    assert rc == 0, lib.cmp_last_error().decode()
+
+
+def tdt(dtype):
+    return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(a).cuda()
+    if dtype is not None:
+        t = t.to(tdt(dtype))
+    return t.contiguous()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rel_err(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+TOL = {FP32: 2e-5, BF16: 1.2e-2}
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(lib, dtype, ta, tb, A, B, M, N, K, bias=None, act=0, aux=None, resid=None, out_fp32=False, splitk=1,
+         p_drop=0.0, seed=0, rng=0, C0=None, ldc=None):
+    ldc = ldc or N
+    if C0 is not None:
+        Cm = C0
+    else:
+        Cm = torch.zeros(M, ldc, device="cuda", dtype=torch.float32 if out_fp32 else tdt(dtype))
+    lda, ldb = A.shape[1], B.shape[1]
+    ck(lib, lib.cmp_k_gemm(stream(), dtype, ta, tb, M, N, K, P(A), lda, P(B), ldb, P(Cm), ldc, P(bias), act, P(aux),
+                           aux.shape[1] if aux is not None else 0, P(resid), resid.shape[1] if resid is not None else 0,
+                           int(out_fp32), splitk, p_drop, seed, rng))
+    torch.cuda.synchronize()
+    return Cm
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 392, 72), (200, 136, 392), (384, 640, 256)])
+def test_gemm_layouts(lib, dtype, ta, tb, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    A = dev(a.t().contiguous() if ta else a, dtype)
+    B = dev(b.t().contiguous() if tb else b, dtype)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    out = gemm(lib, dtype, ta, tb, A, B, M, N, K)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+def test_gemm_identity_asymmetric(lib, dtype):
+    """A = I with an ASYMMETRIC B catches swapped row/col maps in the MFMA C-layout."""
+    n = 128
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 100
+    A = dev(torch.eye(n), dtype)
+    B = dev(b, dtype)
+    for ta, tb in [(0, 0), (1, 0)]:
+        out = gemm(lib, dtype, ta, tb, A, B, n, n, n)
+        assert torch.equal(out.float().cpu(), B.float().cpu())
+    out = gemm(lib, dtype, 0, 1, A, B, n, n, n)
+    assert torch.equal(out.float().cpu(), B.float().cpu().t())
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+def test_gemm_epilogues(lib, dtype):
+    M, N, K = 136, 264, 128
+    g = torch.Generator().manual_seed(5)
+    A, B = dev(torch.randn(M, K, generator=g), dtype), dev(torch.randn(K, N, generator=g) * 0.2, dtype)
+    bias = dev(torch.randn(N, generator=g))
+    resid = dev(torch.randn(M, N, generator=g), dtype)
+    acc = A.double() @ B.double() + bias.double()
+    # bias + gelu, pre-activation to aux
+    aux = torch.zeros(M, N, device="cuda", dtype=tdt(dtype))
+    out = gemm(lib, dtype, 0, 0, A, B, M, N, K, bias=bias, act=1, aux=aux)
+    assert rel_err(aux, acc) < TOL[dtype]
+    assert rel_err(out, torch.tensor(O.gelu(acc.cpu().numpy()))) < TOL[dtype]
+    # bias + residual
+    out = gemm(lib, dtype, 0, 0, A, B, M, N, K, bias=bias, resid=resid)
+    assert rel_err(out, acc + resid.double()) < TOL[dtype]
+    # multiply by gelu'(aux)
+    pre = dev(torch.randn(M, N, generator=g), dtype)
+    out = gemm(lib, dtype, 0, 0, A, B, M, N, K, act=2, aux=pre)
+    ref = (A.double() @ B.double()).cpu() * torch.tensor(O.gelu_grad(pre.double().cpu().numpy()))
+    assert rel_err(out, ref) < TOL[dtype]
+    # fp32 output + split-K accumulation on top of existing contents
+    C0 = torch.ones(M, N, device="cuda", dtype=torch.float32)
+    out = gemm(lib, dtype, 0, 0, A, B, M, N, K, out_fp32=True, splitk=2, C0=C0)
+    assert rel_err(out, A.double() @ B.double() + 1.0) < TOL[dtype]
+    # dropout in the epilogue uses the oracle's mask
+    out = gemm(lib, dtype, 0, 0, A, B, M, N, K, bias=bias, resid=resid, p_drop=0.25, seed=77, rng=9)
+    keep = O.dropout_keep(77, 9, np.arange(M * N, dtype=np.uint64), 0.25).reshape(M, N)
+    ref = acc.cpu() * torch.tensor(keep / 0.75) + resid.double().cpu()
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+def test_gemm_wgrad_shape_large_k(lib, dtype):
+    """wgrad: contraction over tokens (K=4096) with split-K atomics; ragged output (V=390 rows)."""
+    M, N, K = 390, 128, 4096
+    g = torch.Generator().manual_seed(11)
+    At = dev(torch.randn(K, 448, generator=g) * 0.1, dtype)       # stored [K][ld=448], logical A[m,k]=At[k,m]
+    At[:, 390:] = 0
+    B = dev(torch.randn(K, N, generator=g) * 0.1, dtype)
+    C0 = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+    out = gemm(lib, dtype, 1, 0, At, B, M, N, K, out_fp32=True, splitk=8, C0=C0)
+    ref = At.double()[:, :390].t() @ B.double()
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+@pytest.mark.parametrize("rows,E", [(66, 64), (130, 256), (1000, 512), (37, 768)])
+def test_layernorm_fwd_bwd(lib, dtype, rows, E):
+    g = torch.Generator().manual_seed(rows + E)
+    x = dev(torch.randn(rows, E, generator=g) * 2 + 0.5, dtype)
+    gamma, beta = dev(torch.randn(E, generator=g)), dev(torch.randn(E, generator=g))
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    ck(lib, lib.cmp_k_layernorm_fwd(stream(), P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), rows, E, 1e-5, dtype))
+    torch.cuda.synchronize()
+    yr, cache = O.layernorm_fwd(x.double().cpu().numpy(), gamma.double().cpu().numpy(), beta.double().cpu().numpy(), 1e-5)
+    assert rel_err(y, torch.tensor(yr)) < TOL[dtype]
+    assert rel_err(rstd, torch.tensor(cache[1][:, 0])) < 1e-5
+    dy = dev(torch.randn(rows, E, generator=g), dtype)
+    resid = dev(torch.randn(rows, E, generator=g), dtype)
+    dx = torch.empty_like(x)
+    dg = torch.full((E,), 1.0, device="cuda"); db = torch.full((E,), -1.0, device="cuda")
+    ws = torch.empty(lib.cmp_k_layernorm_bwd_ws(rows, E) // 4 + 16, device="cuda")
+    ck(lib, lib.cmp_k_layernorm_bwd(stream(), P(dy), P(x), P(gamma), P(mean), P(rstd), P(resid), P(dx), P(dg), P(db), P(ws),
+                                    rows, E, dtype))
+    torch.cuda.synchronize()
+    dxr, dgr, dbr = O.layernorm_bwd(dy.double().cpu().numpy(), cache, gamma.double().cpu().numpy())
+    assert rel_err(dx, torch.tensor(dxr) + resid.double().cpu()) < TOL[dtype]
+    assert rel_err(dg, torch.tensor(dgr) + 1.0) < 3e-5 * math.sqrt(rows) + (0 if dtype == FP32 else 1e-3)
+    assert rel_err(db, torch.tensor(dbr) - 1.0) < 3e-5 * math.sqrt(rows) + (0 if dtype == FP32 else 1e-3)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, B, T, H, D, keep=None, p=0.0):
+    """float64 restatement of transformer.py:331-371 incl. the exact -1e4 masking; returns o, lse and a closure for grads."""
+    E = H * D
+    x = qkv.double().cpu().reshape(B, T, 3 * E).clone().requires_grad_(True)
+    q, k, v = x.split(E, dim=2)
+    sh = lambda t: t.reshape(B, T, H, D).permute(0, 2, 1, 3)
+    q, k, v = sh(q), sh(k), sh(v)
+    w = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(D))
+    b = torch.tril(torch.ones(T, T, dtype=torch.float64))
+    w = w * b - 1e4 * (1 - b)
+    lse = torch.logsumexp(w, -1)
+    pr = torch.softmax(w, -1)
+    if keep is not None:
+        pr = pr * torch.tensor(keep.reshape(B, H, T, T) / (1 - p))
+    o = (pr @ v).permute(0, 2, 1, 3).reshape(B, T, E)
+    return x, o, lse
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+@pytest.mark.parametrize("B,T,H,D", [(2, 33, 4, 16), (1, 64, 2, 32), (2, 200, 2, 64), (1, 130, 1, 128), (1, 256, 3, 64)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
+    E = H * D
+    g = torch.Generator().manual_seed(B * 1000 + T + D)
+    qkv = dev(torch.randn(B * T, 3 * E, generator=g), dtype)
+    o = torch.zeros(B * T, E, device="cuda", dtype=tdt(dtype))
+    lse = torch.zeros(B * H * T, device="cuda")
+    ck(lib, lib.cmp_k_attn_fwd(stream(), P(qkv), P(o), P(lse), B, T, H, D, 1, dtype, p, 1234, 21))
+    torch.cuda.synchronize()
+    keep = O.dropout_keep(1234, 21, np.arange(B * H * T * T, dtype=np.uint64), p) if p > 0 else None
+    x, oref, lseref = attn_ref(qkv, B, T, H, D, keep, p)
+    tol = TOL[dtype] * (3 if dtype == BF16 else 1)
+    assert rel_err(o, oref.detach().reshape(B * T, E)) < tol
+    assert rel_err(lse, lseref.detach().reshape(-1)) < (1e-5 if dtype == FP32 else 2e-2)
+    do = dev(torch.randn(B * T, E, generator=g), dtype)
+    oref.backward(do.double().cpu().reshape(B, T, E))
+    dqkv = torch.zeros(B * T, 3 * E, device="cuda", dtype=tdt(dtype))
+    delta = torch.zeros(B * H * T, device="cuda")
+    # backward consumes the kernel's own o / lse (as the train step does)
+    ck(lib, lib.cmp_k_attn_bwd(stream(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, dtype, p, 1234, 21))
+    torch.cuda.synchronize()
+    ref = x.grad.reshape(B * T, 3 * E)
+    for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
+        assert rel_err(dqkv[:, sl], ref[:, sl]) < tol * 2, name
+
+
+def test_attention_forced_rescale(lib):
+    """Online-softmax rescale branch: a key far down the sequence dominates a query row (rule: force the branch)."""
+    B, T, H, D = 1, 192, 1, 64
+    qkv = torch.randn(T, 3 * D) * 0.1
+    qkv[150, :D] = 3.0            # query 150
+    qkv[140, D:2 * D] = 5.0       # key 140 -> score 3*5*64/8 = 120 arrives in the 3rd key tile
+    for dtype in (FP32, BF16):
+        q = dev(qkv, dtype)
+        o = torch.zeros(T, D, device="cuda", dtype=tdt(dtype)); lse = torch.zeros(T, device="cuda")
+        ck(lib, lib.cmp_k_attn_fwd(stream(), P(q), P(o), P(lse), B, T, H, D, 1, dtype, 0.0, 0, 0))
+        torch.cuda.synchronize()
+        _, oref, _ = attn_ref(q, B, T, H, D)
+        assert rel_err(o, oref.detach().reshape(T, D)) < TOL[dtype] * 3
+
+
+# ------------------------------------------------------------------------------------------ loss / adam / embedding
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+def test_softmax_xent(lib, dtype):
+    rows, V, ldz = 300, 390, 448
+    g = torch.Generator().manual_seed(3)
+    z = torch.zeros(rows, ldz); z[:, :V] = torch.randn(rows, V, generator=g) * 3
+    z[5, 10] = z[5, 20] = 50.0     # exact tie -> argmax must be the LOWER index
+    y = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32); y[5] = 10
+    zd, yd = dev(z), dev(y)
+    dz = torch.full((rows, ldz), 7.0, device="cuda", dtype=tdt(dtype))
+    rl = torch.zeros(rows, device="cuda"); rc = torch.zeros(rows, device="cuda", dtype=torch.int32)
+    ck(lib, lib.cmp_k_softmax_xent(stream(), P(zd), ldz, P(yd), P(dz), P(rl), P(rc), rows, V, 1.0 / rows, dtype))
+    torch.cuda.synchronize()
+    zz = z[:, :V].double()
+    lse = torch.logsumexp(zz, -1)
+    nll = lse - zz[torch.arange(rows), y.long()]
+    assert rel_err(rl, nll) < 1e-5
+    pred = zz.argmax(-1)
+    pred[5] = 10
+    assert torch.equal(rc.cpu().long(), (pred == y.long()).long())
+    sm = torch.softmax(zz, -1); sm[torch.arange(rows), y.long()] -= 1; sm /= rows
+    assert rel_err(dz[:, :V], sm) < (1e-5 if dtype == FP32 else 1e-2)
+    assert (dz[:, V:] == 0).all()
+
+
+def test_adam_keras_formulation(lib):
+    n = 4096 + 8
+    g = torch.Generator().manual_seed(9)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
+    m0, v0 = torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01
+    p, gd, m, v = dev(p0), dev(gr), dev(m0), dev(v0)
+    sh = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+    ck(lib, lib.cmp_k_adam(stream(), P(p), P(gd), P(m), P(v), P(sh), n, 1e-3, 0.9, 0.999, 1e-7, 7, 0.5))
+    torch.cuda.synchronize()
+    g64 = gr.double() * 0.5
+    m1 = 0.9 * m0.double() + 0.1 * g64
+    v1 = 0.999 * v0.double() + 0.001 * g64 * g64
+    alpha = 1e-3 * math.sqrt(1 - 0.999 ** 7) / (1 - 0.9 ** 7)
+    p1 = p0.double() - alpha * m1 / (v1.sqrt() + 1e-7)
+    assert rel_err(m, m1) < 1e-6 and rel_err(v, v1) < 1e-6 and rel_err(p, p1) < 1e-6
+    assert torch.equal(sh.cpu(), p.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+def test_embedding_fwd_bwd(lib, dtype):
+    B, T, E, V, W = 3, 17, 64, 390, 32
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32)
+    wte, wpe = torch.randn(V, E, generator=g), torch.randn(W, E, generator=g)
+    out = torch.zeros(B * T, E, device="cuda", dtype=tdt(dtype))
+    ck(lib, lib.cmp_k_embed_fwd(stream(), P(dev(ids)), P(dev(wte)), P(dev(wpe)), P(out), B, T, E, 0, dtype, 0.3, 5, 2))
+    torch.cuda.synchronize()
+    keep = torch.tensor(O.dropout_keep(5, 2, np.arange(B * T * E, dtype=np.uint64), 0.3).reshape(B * T, E) / 0.7)
+    ref = (wte[ids.long()] + wpe[:T][None]).reshape(B * T, E).double() * keep
+    assert rel_err(out, ref) < (1e-6 if dtype == FP32 else 1e-2)
+    dh = dev(torch.randn(B * T, E, generator=g), dtype)
+    dwte = torch.zeros(V, E, device="cuda"); dwpe = torch.zeros(W, E, device="cuda")
+    ck(lib, lib.cmp_k_embed_bwd(stream(), P(dev(ids)), P(dh), P(dwte), P(dwpe), B, T, E, 0, dtype, 0.3, 5, 2))
+    torch.cuda.synchronize()
+    d = dh.double().cpu() * keep
+    rw = torch.zeros(V, E, dtype=torch.float64); rw.index_add_(0, ids.reshape(-1).long(), d)
+    rp = torch.zeros(W, E, dtype=torch.float64); rp[:T] = d.reshape(B, T, E).sum(0)
+    assert rel_err(dwte, rw) < 1e-5 and rel_err(dwpe, rp) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
+def test_colsum(lib, dtype):
+    rows, cols = 1000, 392
+    x = dev(torch.randn(rows, cols), dtype)
+    out = torch.ones(cols, device="cuda")
+    ck(lib, lib.cmp_k_colsum(stream(), P(x), cols, P(out), rows, cols, dtype))
+    torch.cuda.synchronize()
+    assert rel_err(out, x.double().sum(0) + 1.0) < 1e-4
