@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Transformer teacher-forced TRAIN STEP (forward + sparse-CE + backward +
+[RCCL all-reduce] + Adam) on synthetic int32 MIDI-event sequences, BASELINE.json's metric:
+"MIDI-event tokens/sec (train, seq=1024)".
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE config 2/3): 6L/8H/d512 decoder, window 1024, B=32 sequences per GPU (weak scaling),
+bf16 activations with fp32 master weights/accumulation, dropout 0.1 (default_config.yml:39-40), lr 1e-3.
+Inputs are generated up front and live in HBM before the timed region.
+
+One JSON line on rank 0 with `roofline` (live HIP-event timing of the dominant kernel class inside the timed
+region) and `cpu_baseline` (the numpy oracle, float32, on the host cores, bounded sample; N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V, E, H, L, W, T = 390, 512, 8, 6, 1024, 1024
+B_PER_GPU = 32
+LR = 1e-3
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+KERNEL_CLASSES = {
+    0: ("gemm_bf16_kernel<A[M,K],B[K,N]> (forward Conv1D/c_fc/c_proj)", "mfma"),
+    1: ("gemm_bf16_kernel<B stored [N,K]> (dgrad)", "mfma"),
+    2: ("gemm_bf16_kernel<A stored [K,M]> (wgrad, split-K)", "mfma"),
+    3: ("attn_fwd_kernel<bf16,64>", "mfma"),
+    4: ("attn_dq_kernel<bf16,64>", "mfma"),
+    5: ("attn_dkv_kernel<bf16,64>", "mfma"),
+    6: ("layernorm_fwd_kernel<bf16>", "hbm"),
+    7: ("adam_kernel", "hbm"),
+}
+
+
+def flops_per_token_train():
+    fwd = L * (24 * E * E + 2 * E * T) + 2 * E * V          # causal attention counted on the unmasked half
+    return 3 * fwd
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (numpy, float32, BLAS threads = host cores) on the same workload shape with B=1:
+    forward + backward + Adam steps until ~seconds_budget of CPU work."""
+    from oracle import transformer_oracle as O          # cpu_baseline leg only
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    params = O.init_params(V, E, W, L, seed=0, dtype=np.float32)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params, dtype=np.float32)
+    rng = np.random.default_rng(1234)
+    Bc = 1
+    x, y = O.synthetic_batch(rng, V, Bc, T)
+    t0 = time.time()
+    orc.train_step(x, y, LR, training=False)            # warm-up (BLAS thread pools, page faults)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while True:
+        orc.train_step(x, y, LR, training=False)
+        n += 1
+        if time.time() - t0 > max(2.0, seconds_budget - warm) or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": Bc * T * n / dt, "unit": "tokens/s", "cores": int(cores), "kind": "port",
+            "sample": "%d train steps (fwd+bwd+Adam, dropout off) of the numpy float32 oracle at B=%d, T=%d, 6L/8H/d512"
+                      % (n, Bc, T)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="sequences per GPU")
+    ap.add_argument("--roofline-kernel", type=int, default=0, help="kernel class timed live (see KERNEL_CLASSES)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import torch
+    import torch.distributed as dist
+    from composer_amd.transformer import Transformer
+    from composer_amd import _lib
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # bootstrap + timing only; gradients go over RCCL
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    Bq = args.batch
+    model = Transformer(V, E, W, L, H, attention_dropout_rate=args.dropout, residual_dropout_rate=args.dropout,
+                        dtype="bf16", seed=1000 + rank, max_batch=Bq, max_seq=T, device=local_rank)
+    model.initialize_parameters(0)                  # identical replicas
+    if world > 1:
+        uid = [Transformer.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        model.init_data_parallel(rank, world, uid[0])
+
+    # synthetic inputs, resident in HBM before the timed region
+    n_data = 4
+    rng = np.random.default_rng(1234)
+    seq = rng.integers(0, V, size=(n_data, world * Bq, T + 1), dtype=np.int32)
+    mine = seq[:, rank * Bq:(rank + 1) * Bq]
+    xs = [torch.from_numpy(np.ascontiguousarray(mine[i, :, :-1])).to(dev) for i in range(n_data)]
+    ys = [torch.from_numpy(np.ascontiguousarray(mine[i, :, 1:])).to(dev) for i in range(n_data)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        model.train_step_device(xs[i % n_data].data_ptr(), ys[i % n_data].data_ptr(), Bq, T, LR)
+
+    def fence():
+        model.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    lib = _lib.load()
+    lib.cmp_prof_begin(args.roofline_kernel)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    model.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ms, n_launch, work = C.c_double(), C.c_int64(), C.c_double()
+    lib.cmp_prof_end(C.byref(ms), C.byref(n_launch), C.byref(work))
+    loss, acc = model.last_metrics()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        tokens = world * Bq * T * args.steps
+        value = tokens / dt
+        name, bound = KERNEL_CLASSES[args.roofline_kernel]
+        if n_launch.value > 0 and ms.value > 0:
+            if bound == "mfma":
+                achieved = work.value / (ms.value * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None}
+            else:
+                achieved = work.value / (ms.value * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+            roof.update({"kernel": name, "launches": int(n_launch.value),
+                         "avg_launch_us": 1e3 * ms.value / n_launch.value,
+                         "algorithmic_per_launch": work.value / n_launch.value})
+        else:
+            roof = None
+        out = {
+            "metric": "MIDI-event tokens/sec (train, seq=1024)", "value": value, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "6L/8H/d512 Transformer train step, seq=1024, B=%d/GPU, dropout %.2f, Adam lr 1e-3, "
+                                   "synthetic int32 event ids (vocab 390), random-init weights" % (Bq, args.dropout),
+                       "global_batch": world * Bq, "seq_len": T, "parallelism": "dp%d" % world,
+                       "tokens_per_step": world * Bq * T},
+            "model_tflops": value * flops_per_token_train() / 1e12,
+            "model_mfma_frac": value * flops_per_token_train() / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "final_loss": loss,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,8 @@ SIGNATURES = {
     "cmp_forward_logits": (_i, [_P, _P, _i, _i, _P]),
     "cmp_decode_begin": (_i, [_P, _P, _i, _i, _f, _u64]),
     "cmp_decode_steps": (_i, [_P, _i, _P]),
+    "cmp_prof_begin": (_i, [_i]),
+    "cmp_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "cmp_k_embed_fwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_embed_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_layernorm_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _f, _i]),

@@ -438,7 +438,10 @@ template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
     size_t smem = 2 * 64 * Geo<T, D>::S * sizeof(T);
     dim3 grid(cdiv(Tn, 128), B * H);
+    const double flops = 2.0 * B * H * (double)Tn * Tn * D;      // QK^T + PV on the unmasked half
+    PROF_START(3, s);
     attn_fwd_kernel<T, D><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
+    PROF_STOP(3, s, flops);
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -450,10 +453,15 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
     KERNEL_CHECK();
     dim3 grid(cdiv(Tn, 128), B * H);
     size_t smem = 2 * 64 * Geo<T, D>::S * sizeof(T);
+    const double fl = (double)B * H * (double)Tn * Tn * D;        // one product over the unmasked half
+    PROF_START(4, s);
     attn_dq_kernel<T, D><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    PROF_STOP(4, s, 3.0 * fl);
     KERNEL_CHECK();
+    PROF_START(5, s);
     attn_dkv_kernel<T, D><<<grid, 256, smem + 128 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta,
                                                                           (T*)dqkv, Tn, H, scale, d);
+    PROF_STOP(5, s, 4.0 * fl);
     KERNEL_CHECK();
     return CMP_OK;
 }

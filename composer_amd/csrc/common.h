@@ -43,6 +43,13 @@ void cmp_set_error(const char* fmt, ...);
 
 #define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
 
+// live per-kernel-class timing (cmp_prof_begin / cmp_prof_end, model.hip)
+extern int g_prof_cls;
+void prof_start(int cls, hipStream_t s);
+void prof_stop(int cls, hipStream_t s, double work);
+#define PROF_START(cls, s) do { if (g_prof_cls == (cls)) prof_start((cls), (s)); } while (0)
+#define PROF_STOP(cls, s, work) do { if (g_prof_cls == (cls)) prof_stop((cls), (s), (work)); } while (0)
+
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

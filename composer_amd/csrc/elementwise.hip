@@ -444,10 +444,12 @@ extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gam
     if (rows == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = std::min(cdiv(rows, 4), 8192);
+    PROF_START(6, s);
     if (dtype == CMP_BF16)
         layernorm_fwd_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, E, eps);
     else
         layernorm_fwd_kernel<float><<<grid, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, mean, rstd, rows, E, eps);
+    PROF_STOP(6, s, (double)rows * (2.0 * E * dtype_size(dtype) + 8.0));
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -505,7 +507,9 @@ extern "C" int cmp_k_adam(void* stream, float* p, const float* g, float* m, floa
     double alpha = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
     int64_t n4 = n / 4;
     int grid = (int)std::min<int64_t>(cdiv64(n4, 256), 8192);
+    PROF_START(7, s);
     adam_kernel<<<grid, 256, 0, s>>>(p, g, m, v, (bf16_t*)shadow_bf16, n4, n, (float)alpha, beta1, beta2, eps, grad_scale);
+    PROF_STOP(7, s, (double)n * (28.0 + (shadow_bf16 ? 2.0 : 0.0)));
     KERNEL_CHECK();
     return CMP_OK;
 }

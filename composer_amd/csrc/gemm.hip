@@ -313,11 +313,14 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
         size_t smem = 4 * G_IMG;
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)Bm;
+        const int cls = ta ? 2 : (tb ? 1 : 0);
+        PROF_START(cls, s);
         // A_KM = !ta ; B_KM = tb
         if (!ta && !tb) gemm_bf16_kernel<true, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
         else if (!ta && tb) gemm_bf16_kernel<true, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
         else if (ta && !tb) gemm_bf16_kernel<false, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
         else gemm_bf16_kernel<false, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
+        PROF_STOP(cls, s, 2.0 * M * N * K);
     }
     KERNEL_CHECK();
     return CMP_OK;

@@ -31,6 +31,51 @@ extern "C" int cmp_device_count(void) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// live kernel timing
+// -------------------------------------------------------------------------------------------------
+int g_prof_cls = -1;
+static std::vector<hipEvent_t> g_prof_ev;     // start/stop pairs
+static size_t g_prof_used = 0;
+static double g_prof_work = 0.0;
+void prof_start(int, hipStream_t s) {
+    if (g_prof_used + 2 > g_prof_ev.size()) {
+        for (int i = 0; i < 256; i++) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            g_prof_ev.push_back(e);
+        }
+    }
+    (void)hipEventRecord(g_prof_ev[g_prof_used], s);
+}
+void prof_stop(int, hipStream_t s, double work) {
+    if (g_prof_used + 2 > g_prof_ev.size()) return;
+    (void)hipEventRecord(g_prof_ev[g_prof_used + 1], s);
+    g_prof_used += 2;
+    g_prof_work += work;
+}
+extern "C" int cmp_prof_begin(int cls) {
+    g_prof_cls = cls;
+    g_prof_used = 0;
+    g_prof_work = 0.0;
+    return CMP_OK;
+}
+extern "C" int cmp_prof_end(double* total_ms, int64_t* launches, double* work) {
+    g_prof_cls = -1;
+    HIP_CHECK(hipDeviceSynchronize());
+    double t = 0.0;
+    for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, g_prof_ev[i], g_prof_ev[i + 1]));
+        t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = (int64_t)(g_prof_used / 2);
+    if (work) *work = g_prof_work;
+    g_prof_used = 0;
+    return CMP_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
 // context
 // -------------------------------------------------------------------------------------------------
 extern "C" int cmp_ctx_create(int device, cmp_ctx** out) {

@@ -121,6 +121,14 @@ int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logi
 int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int mode, float temperature, uint64_t seed);
 int cmp_decode_steps(cmp_model* m, int n, int32_t* ids_out);
 
+/* ---- live kernel timing (bench.py roofline): HIP events around every launch of ONE kernel class on the
+ * stream it is launched on.  cls: 0 gemm forward (A[M,K].B[K,N]), 1 gemm dgrad (B stored [N,K]), 2 gemm wgrad
+ * (A stored [K,M]), 3 attention forward, 4 attention dQ, 5 attention dK/dV, 6 layernorm fwd, 7 adam.
+ * cmp_prof_end syncs the device and returns summed milliseconds, launch count and summed algorithmic work
+ * (flops for 0-5, bytes for 6-7). */
+int cmp_prof_begin(int cls);
+int cmp_prof_end(double* total_ms, int64_t* launches, double* work);
+
 /* ---- kernel-level entry points (dev pointers; dtype = cmp_dtype of activations) ----------------
  * Used by tests/ and bench.py to check and time single kernels against the oracle/roofline. */
 int cmp_k_embed_fwd(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out,

@@ -287,14 +287,15 @@ def test_embedding_fwd_bwd(lib, dtype):
     ids = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32)
     wte, wpe = torch.randn(V, E, generator=g), torch.randn(W, E, generator=g)
     out = torch.zeros(B * T, E, device="cuda", dtype=tdt(dtype))
-    ck(lib, lib.cmp_k_embed_fwd(stream(), P(dev(ids)), P(dev(wte)), P(dev(wpe)), P(out), B, T, E, 0, dtype, 0.3, 5, 2))
+    ids_d, wte_d, wpe_d = dev(ids), dev(wte), dev(wpe)      # keep alive across the launches
+    ck(lib, lib.cmp_k_embed_fwd(stream(), P(ids_d), P(wte_d), P(wpe_d), P(out), B, T, E, 0, dtype, 0.3, 5, 2))
     torch.cuda.synchronize()
     keep = torch.tensor(O.dropout_keep(5, 2, np.arange(B * T * E, dtype=np.uint64), 0.3).reshape(B * T, E) / 0.7)
     ref = (wte[ids.long()] + wpe[:T][None]).reshape(B * T, E).double() * keep
     assert rel_err(out, ref) < (1e-6 if dtype == FP32 else 1e-2)
     dh = dev(torch.randn(B * T, E, generator=g), dtype)
     dwte = torch.zeros(V, E, device="cuda"); dwpe = torch.zeros(W, E, device="cuda")
-    ck(lib, lib.cmp_k_embed_bwd(stream(), P(dev(ids)), P(dh), P(dwte), P(dwpe), B, T, E, 0, dtype, 0.3, 5, 2))
+    ck(lib, lib.cmp_k_embed_bwd(stream(), P(ids_d), P(dh), P(dwte), P(dwpe), B, T, E, 0, dtype, 0.3, 5, 2))
     torch.cuda.synchronize()
     d = dh.double().cpu() * keep
     rw = torch.zeros(V, E, dtype=torch.float64); rw.index_add_(0, ids.reshape(-1).long(), d)

@@ -221,7 +221,15 @@ def test_full_size_c2_properties():
     rng = np.random.default_rng(1234)
     x, y = O.synthetic_batch(rng, V, B, T)
     l0, _ = m.evaluate([(x, y)])
-    assert abs(l0 - np.log(390)) < 0.2
+    assert 5.9 < l0 < 7.2          # tied embeddings favour the CURRENT token, so the initial loss sits above ln(390)
+    # full model width against the oracle on a slice the oracle finishes in seconds (same seeded init on both sides)
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=0).items()}
+    m.set_weights(params)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
+    ref, _ = orc.loss_acc(orc.forward(x[:1, :256])[0], y[:1, :256])
+    got, _ = m.evaluate([(x[:1, :256], y[:1, :256])])
+    assert abs(got - ref) <= 1e-2 * ref, (got, ref)
+    l0, _ = m.evaluate([(x, y)])
     perm = np.array([2, 0, 3, 1])
     lp, _ = m.evaluate([(x[perm], y[perm])])
     assert abs(lp - l0) < 1e-3
