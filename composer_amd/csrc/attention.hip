@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
     float m = -INFINITY, lsum = 0.f;
     const int kv_end = min(Tn, blockIdx.x * 128 + 128);
-    const uint64_t drop_row = ((uint64_t)blockIdx.y * Tn + q) * (uint64_t)Tn;
+    const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
 
     for (int kt0 = 0; kt0 < kv_end; kt0 += 64) {
         __syncthreads();
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
             for (int r = 0; r < 16; r++) {
                 float p = exp_f<EXACT>(s[r] - mnew);
                 ps += p;
-                if (drop.thr) p = apply_drop(drop, drop_row + (uint64_t)(k0 + rho(r, h)), p);
+                if (drop.thr) p = attn_elem_hash(rowh, (uint32_t)(k0 + rho(r, h))) >= drop.thr ? p * drop.scale : 0.f;
                 s[r] = p;
             }
             lsum = lsum * alpha + ps;
@@ -260,20 +260,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 template <typename T>
 __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ delta,
                                   int B, int Tn, int H, int D) {
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)B * H * Tn) return;
-    int t = (int)(gid % Tn);
-    int hd = (int)((gid / Tn) % H);
-    int b = (int)(gid / ((int64_t)Tn * H));
-    const int64_t off = ((int64_t)b * Tn + t) * (H * D) + hd * D;
+    // one wave per token row [E = H*D]: lane l owns the 16-byte chunks l, l+64, ...; the D/VN lanes of a head are
+    // adjacent, so a segmented xor-shuffle reduction gives the per-head sums (coalesced 1 KiB reads).
     constexpr int VN = Vec16<T>::N;
-    float a = 0.f;
-    for (int d = 0; d < D; d += VN) {
-        Vec16<T> x = ld16(o + off + d), y = ld16(d_o + off + d);
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int E = H * D, chunks = E / VN, cph = D / VN;          // chunks per head: 2..32 (power of two)
+    for (int64_t row = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); row < (int64_t)B * Tn; row += (int64_t)gridDim.x * wpb) {
+        const int b = (int)(row / Tn), t = (int)(row % Tn);
+        for (int c0 = 0; c0 < chunks; c0 += 64) {
+            const int c = c0 + lane;
+            float a = 0.f;
+            if (c < chunks) {
+                Vec16<T> x = ld16(o + row * E + c * VN), y = ld16(d_o + row * E + c * VN);
 #pragma unroll
-        for (int j = 0; j < VN; j++) a += x.get(j) * y.get(j);
+                for (int j = 0; j < VN; j++) a += x.get(j) * y.get(j);
+            }
+            for (int s = 1; s < cph; s <<= 1) a += __shfl_xor(a, s);
+            if (c < chunks && (c % cph) == 0) delta[((int64_t)b * H + c / cph) * Tn + t] = a;
+        }
     }
-    delta[gid] = a;
 }
 
 // =================================================================================================
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const T* __restrict__ qkv,
 #pragma unroll
         for (int r = 0; r < 16; r++) dq[dt][r] = 0.f;
     const int kv_end = min(Tn, blockIdx.x * 128 + 128);
-    const uint64_t drop_row = ((uint64_t)blockIdx.y * Tn + q) * (uint64_t)Tn;
+    const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
 
     for (int kt0 = 0; kt0 < kv_end; kt0 += 64) {
         __syncthreads();
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const T* __restrict__ qkv,
                 bool masked = (key > q) || (key >= Tn) || !qvalid;
                 float p = masked ? 0.f : exp_f<EXACT>(s[r] * scale - lse_q);
                 float dpv = dp[r];
-                if (drop.thr) dpv = apply_drop(drop, drop_row + (uint64_t)key, dpv);
+                if (drop.thr) dpv = attn_elem_hash(rowh, (uint32_t)key) >= drop.thr ? dpv * drop.scale : 0.f;
                 s[r] = p * (dpv - del_q);
             }
 #pragma unroll
@@ -358,6 +363,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv
     T* Os = Qs + 64 * G::S;                          // dO [64][S]
     float* Ls = reinterpret_cast<float*>(Os + 64 * G::S);   // lse [64]
     float* Dl = Ls + 64;                             // delta [64]
+    uint32_t* Rh = reinterpret_cast<uint32_t*>(Dl + 64);   // dropout row hashes [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = blockIdx.y / H, hd = blockIdx.y % H;
     const int E = H * D;
@@ -377,8 +383,6 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv
     for (int dt = 0; dt < G::DT; dt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    const uint64_t drop_bh = (uint64_t)blockIdx.y * Tn;
-
     for (int qt0 = (blockIdx.x * 128) & ~63; qt0 < Tn; qt0 += 64) {
         __syncthreads();
         stage_rows<T, D>(Qs, qg, rs, qt0, Tn, 64, tid);
@@ -387,6 +391,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv
             int qq = qt0 + tid;
             Ls[tid] = qq < Tn ? lse[(int64_t)blockIdx.y * Tn + qq] : 0.f;
             Dl[tid] = qq < Tn ? delta[(int64_t)blockIdx.y * Tn + qq] : 0.f;
+            Rh[tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + qq));
         }
         __syncthreads();
 #pragma unroll
@@ -408,9 +413,9 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv
                 float dpv = dp[r];
                 float pd = p;
                 if (drop.thr) {
-                    uint64_t idx = (drop_bh + (uint64_t)qq) * (uint64_t)Tn + (uint64_t)key;
-                    dpv = apply_drop(drop, idx, dpv);
-                    pd = apply_drop(drop, idx, p);
+                    const bool keep = attn_elem_hash(Rh[ql], (uint32_t)key) >= drop.thr;
+                    dpv = keep ? dpv * drop.scale : 0.f;
+                    pd = keep ? p * drop.scale : 0.f;
                 }
                 pt[r] = pd;                         // dropped probabilities feed dV
                 s[r] = p * (dpv - Dl[ql]);          // dS feeds dK
@@ -448,8 +453,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
 template <typename T, int D>
 static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                       void* dqkv, int B, int Tn, int H, float scale, DropCfg d) {
-    int64_t n = (int64_t)B * H * Tn;
-    attn_delta_kernel<T><<<(int)cdiv64(n, 256), 256, 0, s>>>((const T*)o, (const T*)d_o, delta, B, Tn, H, D);
+    attn_delta_kernel<T><<<(int)std::min<int64_t>(cdiv64((int64_t)B * Tn, 4), 4096), 256, 0, s>>>((const T*)o, (const T*)d_o, delta, B, Tn, H, D);
     KERNEL_CHECK();
     dim3 grid(cdiv(Tn, 128), B * H);
     size_t smem = 2 * 64 * Geo<T, D>::S * sizeof(T);
@@ -459,7 +463,7 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
     PROF_STOP(4, s, 3.0 * fl);
     KERNEL_CHECK();
     PROF_START(5, s);
-    attn_dkv_kernel<T, D><<<grid, 256, smem + 128 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta,
+    attn_dkv_kernel<T, D><<<grid, 256, smem + 192 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta,
                                                                           (T*)dqkv, Tn, H, scale, d);
     PROF_STOP(5, s, 4.0 * fl);
     KERNEL_CHECK();

@@ -78,6 +78,20 @@ static inline uint32_t drop_stream(int64_t step, int layer, int site) {
     return (uint32_t)(((step * 64 + layer) * 4 + site) & 0xFFFFFFFFll);
 }
 
+// attention-probability dropout (site 1): one full-quality hash per (batch*head, query) row, then a light
+// per-key mix -- the mask is a pure function of (row, key) so forward, dQ and dK/dV regenerate it in any layout.
+// oracle: transformer_oracle.py::dropout_keep_attn
+__host__ __device__ __forceinline__ uint32_t attn_row_hash(uint32_t seed, uint32_t stream, uint32_t row) {
+    return mix32(mix32(row ^ seed) ^ stream);
+}
+__host__ __device__ __forceinline__ uint32_t attn_elem_hash(uint32_t rowhash, uint32_t key) {
+    uint32_t x = rowhash ^ (key * 0x9E3779B1u);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    return x;
+}
+
 struct DropCfg {
     uint32_t thr;     // keep iff hash >= thr ; thr == 0 -> dropout disabled
     uint32_t seed;

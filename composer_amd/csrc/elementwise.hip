@@ -206,14 +206,15 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
     }
 }
 
+// grid (ceil(2E/256), slices): each thread folds nparts/slices partials, then one atomic per slice
 __global__ void ln_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int nparts, int E) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 2 * E) return;
     float a = 0.f;
-    for (int p = 0; p < nparts; p++) a += ws[(size_t)p * 2 * E + e];
-    if (e < E) dgamma[e] += a;
-    else dbeta[e - E] += a;
+    for (int p = blockIdx.y; p < nparts; p += gridDim.y) a += ws[(size_t)p * 2 * E + e];
+    if (e < E) atomicAdd(dgamma + e, a);
+    else atomicAdd(dbeta + (e - E), a);
 }
 
 // =================================================================================================
@@ -361,33 +362,41 @@ __global__ void cast_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __
 
 // =================================================================================================
 // column sums (bias gradients): out[c] += sum_r X[r, c]
-// grid (ceil(cols/128), splits); 256 threads: lanes over 2 adjacent columns each, 4 waves over rows
+// grid (ceil(cols/(64*VN)), row splits); a lane owns one 16-byte chunk of columns, the 4 waves take rows
+// r, r+4, ... (4 loads in flight per lane); cross-wave fold through LDS, one f32 atomic per column per split.
 // =================================================================================================
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out, int rows, int cols) {
-    __shared__ float sm[4][128];
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out, int rows, int cols) {
+    constexpr int VN = Vec16<T>::N;
+    __shared__ float sm[4][64 * VN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * 128 + lane * 2;
+    const int c0 = (blockIdx.x * 64 + lane) * VN;
     const int rows_per = cdiv(rows, (int)gridDim.y);
     const int r0 = blockIdx.y * rows_per;
     const int r1 = min(rows, r0 + rows_per);
-    float a0 = 0.f, a1 = 0.f;
+    float acc[VN];
+#pragma unroll
+    for (int j = 0; j < VN; j++) acc[j] = 0.f;
     if (c0 < cols) {
-        for (int r = r0 + wave; r < r1; r += 4) {
-            const T* p = X + (int64_t)r * ldx + c0;
-            a0 += to_f32<T>(p[0]);
-            if (c0 + 1 < cols) a1 += to_f32<T>(p[1]);
+        int r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            Vec16<T> v0 = ld16(X + (int64_t)r * ldx + c0), v1 = ld16(X + (int64_t)(r + 4) * ldx + c0);
+            Vec16<T> v2 = ld16(X + (int64_t)(r + 8) * ldx + c0), v3 = ld16(X + (int64_t)(r + 12) * ldx + c0);
+#pragma unroll
+            for (int j = 0; j < VN; j++) acc[j] += (v0.get(j) + v1.get(j)) + (v2.get(j) + v3.get(j));
+        }
+        for (; r < r1; r += 4) {
+            Vec16<T> v0 = ld16(X + (int64_t)r * ldx + c0);
+#pragma unroll
+            for (int j = 0; j < VN; j++) acc[j] += v0.get(j);
         }
     }
-    sm[wave][lane * 2] = a0;
-    sm[wave][lane * 2 + 1] = a1;
+#pragma unroll
+    for (int j = 0; j < VN; j++) sm[wave][lane * VN + j] = acc[j];
     __syncthreads();
-    if (threadIdx.x < 128) {
-        int c = blockIdx.x * 128 + threadIdx.x;
-        if (c < cols) {
-            float s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-            atomicAdd(out + c, s);
-        }
+    for (int i = threadIdx.x; i < 64 * VN; i += 256) {
+        int c = blockIdx.x * 64 * VN + i;
+        if (c < cols) atomicAdd(out + c, sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i]);
     }
 }
 
@@ -474,7 +483,7 @@ extern "C" int cmp_k_layernorm_bwd(void* stream, const void* dy, const void* x, 
         layernorm_bwd_kernel<float><<<grid, 256, smem, s>>>((const float*)dy, (const float*)x, gamma, mean, rstd,
                                                              (const float*)resid, (float*)dx, (float*)ws, rows, E);
     KERNEL_CHECK();
-    ln_param_reduce_kernel<<<cdiv(2 * E, 256), 256, 0, s>>>((const float*)ws, dgamma, dbeta, grid, E);
+    ln_param_reduce_kernel<<<dim3(cdiv(2 * E, 256), std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, grid, E);
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -526,8 +535,11 @@ int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n) {
 extern "C" int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype) {
     if (rows == 0 || cols == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
-    int splits = std::max(1, std::min(rows / 256, 64));
-    dim3 grid(cdiv(cols, 128), splits);
+    const int vn = dtype == CMP_BF16 ? 8 : 4;
+    CMP_REQUIRE(cols % vn == 0 && ldx % vn == 0, "colsum: cols=%d and ldx=%d must be multiples of %d", cols, ldx, vn);
+    const int gx = cdiv(cols, 64 * vn);
+    int splits = std::max(1, std::min(std::min(rows / 64, 128), std::max(1, 1024 / gx)));
+    dim3 grid(gx, splits);
     if (dtype == CMP_BF16)
         colsum_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, ldx, out, rows, cols);
     else

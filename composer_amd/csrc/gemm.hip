@@ -272,12 +272,185 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, con
 }
 
 // =================================================================================================
+// bf16 fast path: same tile and LDS images, but
+//   * operands go HBM -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction); the LDS
+//     destination is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address and the
+//     same XOR on the fragment read (rule "both sides or neither");
+//   * out-of-range rows come back as zeros from the buffer descriptor's range check (exact in the slow
+//     dimension of either layout);
+//   * SWAP: mfma(B_frag, A_frag) puts the C ROW on the lane and 4 consecutive C COLUMNS in the 4 accumulator
+//     registers -> 8-byte (bf16) / 16-byte (fp32) epilogue stores and vector bias/aux/residual loads;
+//     split-K launches keep the un-swapped map (16 consecutive floats per row per atomic instruction);
+//   * 1-D grid with a bijective XCD-aware remap: workgroups that share an A row-panel run on one XCD's L2.
+// =================================================================================================
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <bool KM>
+__device__ __forceinline__ void glds_tile(__amdgpu_buffer_rsrc_t rs, char* img, int ld_bytes, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = wave * 4 + i;
+        int voff;
+        if (KM) {
+            const int r = 8 * p + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            voff = r * ld_bytes + (k0 + c * 8) * 2;
+        } else {
+            const int k = 4 * p + (lane >> 4);
+            const int c = (lane & 15) ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1);
+            voff = (k0 + k) * ld_bytes + c * 16;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(img + p * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store4(const Epilogue& ep, void* C, int ldc, int row, int col, f32x4 v) {
+    if (ep.bias) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + col);
+        v += b;
+    }
+    if (ep.act == 1) {
+        if (ep.aux) {
+            bf16x4 a;
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x4*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col) = a;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = gelu_f<false>(v[j]);
+    } else if (ep.act == 2) {
+        bf16x4 a = *reinterpret_cast<const bf16x4*>((const bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] *= gelu_grad_f<false>((float)a[j]);
+    }
+    if (ep.drop.thr) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+    }
+    if (ep.resid) {
+        bf16x4 r = *reinterpret_cast<const bf16x4*>((const bf16_t*)ep.resid + (int64_t)row * ep.ldr + col);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] += (float)r[j];
+    }
+    if (ep.out_fp32) {
+        *reinterpret_cast<f32x4*>((float*)C + (int64_t)row * ldc + col) = v;
+    } else {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x4*>((bf16_t*)C + (int64_t)row * ldc + col) = o;
+    }
+}
+
+template <bool A_KM, bool B_KM, bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
+                                                                const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
+                                                                Epilogue ep, int ktiles_per_split, int tiles_n, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A img | B img]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // bijective XCD remap (blocks b and b+8 share an XCD): XCD x works on a contiguous run of tiles
+    int tile;
+    {
+        const int orig = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, x = orig & 7;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (orig >> 3);
+    }
+    const int m0 = (tile / tiles_n) * G_BM, n0 = (tile % tiles_n) * G_BN;
+    const int nk = cdiv(K, G_BK);
+    const int kt0 = blockIdx.y * ktiles_per_split;
+    const int kt1 = min(nk, kt0 + ktiles_per_split);
+
+    // buffer descriptors: tile-relative bases, range = the rest of the tensor (clamped): slow-dim overflow reads 0
+    const int64_t a_rows = A_KM ? (int64_t)M : (int64_t)K, b_rows = B_KM ? (int64_t)N : (int64_t)K;
+    const bf16_t* abase = A_KM ? A + (int64_t)m0 * lda : A + m0;
+    const bf16_t* bbase = B_KM ? B + (int64_t)n0 * ldb : B + n0;
+    const int64_t a_bytes = (A_KM ? (a_rows - m0) * lda : a_rows * lda - m0) * 2;
+    const int64_t b_bytes = (B_KM ? (b_rows - n0) * ldb : b_rows * ldb - n0) * 2;
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, (int)min(a_bytes, (int64_t)0x7FFFFFF0), 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bbase, 0, (int)min(b_bytes, (int64_t)0x7FFFFFF0), 0x00020000);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (kt0 < kt1) {
+        glds_tile<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
+        glds_tile<B_KM>(rb, smem + G_IMG, ldb * 2, kt0 * G_BK, wave, lane);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; kt++) {
+        const int st = (kt - kt0) & 1;
+        const char* ia = smem + st * 2 * G_IMG;
+        const char* ib = ia + G_IMG;
+        if (kt + 1 < kt1) {
+            char* na = smem + (st ^ 1) * 2 * G_IMG;
+            glds_tile<A_KM>(ra, na, lda * 2, (kt + 1) * G_BK, wave, lane);
+            glds_tile<B_KM>(rb, na + G_IMG, ldb * 2, (kt + 1) * G_BK, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                fa[i] = g_frag<A_KM>(ia, wm * 4 + i, ks, lane);
+                fb[i] = g_frag<B_KM>(ib, wn * 4 + i, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();     // also drains the LDS-DMA of the next tile (vmcnt(0) is emitted with the barrier)
+    }
+    if (SWAP) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (row < M) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                    if (col < N) epilogue_store4<bf16_t>(ep, C, ldc, row, col, acc[i][j]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    int col = n0 + wn * 64 + j * 16 + (lane & 15);
+                    if (row < M && col < N) epilogue_store<bf16_t, false>(ep, C, ldc, row, col, acc[i][j][r]);
+                }
+    }
+}
+
+template <bool A_KM, bool B_KM>
+static void launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M, int N, int K, const bf16_t* a, int lda,
+                        const bf16_t* b, int ldb, void* C, int ldc, const Epilogue& ep, int per, int tiles_n, int ntiles) {
+    if (swap)
+        gemm_bf16_fast_kernel<A_KM, B_KM, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+    else
+        gemm_bf16_fast_kernel<A_KM, B_KM, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+}
+
+// =================================================================================================
 // host launcher
 // =================================================================================================
 extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda,
                           const void* Bm, int ldb, void* C, int ldc, const float* bias, int act, void* aux, int ldaux,
                           const void* resid, int ldr, int out_fp32, int splitk, float p_drop, uint64_t seed,
-                          uint32_t rng_stream) {
+                          uint32_t rng_stream, int flags) {
     if (M == 0 || N == 0) return CMP_OK;
     CMP_REQUIRE(K > 0, "gemm: K must be positive");
     hipStream_t s = (hipStream_t)stream;
@@ -314,7 +487,24 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)Bm;
         const int cls = ta ? 2 : (tb ? 1 : 0);
+        // fast path: direct-to-LDS staging needs every 64-deep k-step of a K-contiguous operand inside its row
+        // (K % 64 == 0, or the caller vouches for zero padding up to a multiple of 64 with CMP_GEMM_KPAD_ZERO) and
+        // 32-bit byte offsets.
+        const bool kpad = (K % 64 == 0) || ((flags & 1) && (ta || lda >= (K + 63) / 64 * 64) && (!tb || ldb >= (K + 63) / 64 * 64));
+        const bool km_ok = (ta && !tb) || kpad;
+        const int64_t a_span = (int64_t)(ta ? K : M) * lda * 2, b_span = (int64_t)(tb ? N : K) * ldb * 2;
+        const bool fast = km_ok && a_span < 0x7FFFFFF0ll && b_span < 0x7FFFFFF0ll && N % 4 == 0 && ldc % 4 == 0 &&
+                          (!aux || ldaux % 4 == 0) && (!resid || ldr % 4 == 0) && !(flags & 2);
         PROF_START(cls, s);
+        if (fast) {
+            const int tiles_n = cdiv(N, G_BN), ntiles = tiles_n * cdiv(M, G_BM);
+            dim3 g1(ntiles, cdiv(nk, per));
+            const bool swap = !ep.atomic;
+            if (!ta && !tb) launch_fast<true, false>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+            else if (!ta && tb) launch_fast<true, true>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+            else if (ta && !tb) launch_fast<false, false>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+            else launch_fast<false, true>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+        } else
         // A_KM = !ta ; B_KM = tb
         if (!ta && !tb) gemm_bf16_kernel<true, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
         else if (!ta && tb) gemm_bf16_kernel<true, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);

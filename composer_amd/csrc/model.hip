@@ -380,9 +380,9 @@ static int drop_apply(cmp_model* m, const void* in, void* out, int64_t n, float 
 // -------------------------------------------------------------------------------------------------
 static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                 int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
-                int splitk, float p_drop, uint32_t rng_stream) {
+                int splitk, float p_drop, uint32_t rng_stream, int flags = 0) {
     return cmp_k_gemm(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
-                      out_fp32, splitk, p_drop, m->cfg.seed, rng_stream);
+                      out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags);
 }
 
 int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step) {
@@ -455,7 +455,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     CHECK_RC(gemm(m, 1, 0, V, E, M, m->dlogits, m->ldz, m->hf, E, m->G + m->off_wte, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                   std::max(2, wgrad_splits(M, V, E)), 0.f, 0));
     CHECK_RC(gemm(m, 0, 0, M, E, V, m->dlogits, m->ldz, m->w(m->off_wte), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0,
-                  1, 0.f, 0));
+                  1, 0.f, 0, CMP_GEMM_KPAD_ZERO));    // dlogits rows are zero-padded to ldz (softmax_xent kernel)
     CHECK_RC(cmp_k_layernorm_bwd(s, m->tmpE, m->xs[m->L], m->P + m->off_lnf_g, m->lnf_mean, m->lnf_rstd, nullptr, m->dx,
                                  m->G + m->off_lnf_g, m->G + m->off_lnf_b, m->ln_ws, M, E, dt));
     if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total));

@@ -145,11 +145,17 @@ int64_t cmp_k_layernorm_bwd_ws(int rows, int E);
 /* C[M,N] = epilogue(A.B): ta=0: A is [M,K] (lda); ta=1: A stored [K,M].  tb=0: B stored [K,N]; tb=1: B stored [N,K].
  * epilogue: +bias[N] (fp32, may be NULL); act: 0 none, 1 gelu (pre-activation stored to aux if aux!=NULL),
  * 2 multiply by gelu'(aux[m,n]); dropout (p>0) then +resid[m,n] (may be NULL).  out_fp32: C is fp32 regardless of
- * dtype.  splitk>1: fp32 atomic accumulation into C (C must be pre-zeroed or hold the value to add to). */
+ * dtype.  splitk>1: fp32 atomic accumulation into C (C must be pre-zeroed or hold the value to add to).
+ * dropout index = row*ldc + col (ldc == N for the model's outputs). */
 int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
                const void* A, int lda, const void* Bm, int ldb, void* C, int ldc,
                const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr,
-               int out_fp32, int splitk, float p_drop, uint64_t seed, uint32_t rng_stream);
+               int out_fp32, int splitk, float p_drop, uint64_t seed, uint32_t rng_stream, int flags);
+/* flags: CMP_GEMM_KPAD_ZERO -- K-contiguous bf16 operands are stored with their rows zero-padded to a multiple of
+ * 64 elements (lets a ragged K, e.g. the vocabulary, use the direct-to-LDS path); CMP_GEMM_GENERIC forces the
+ * register-staged generic kernel (tests). */
+#define CMP_GEMM_KPAD_ZERO 1
+#define CMP_GEMM_GENERIC 2
 int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype);
 /* causal attention on qkv [B,T,3E] (head-merged, transformer.py:417): o [B,T,E], lse fp32 [B,H,T] */
 int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D,

@@ -92,6 +92,20 @@ def dropout_keep(seed, stream, idx, p):
     return h >= thr
 
 
+def dropout_keep_attn(seed, stream, BH, T, p):
+    """Attention-probability mask [BH, T(query), T(key)] (csrc/common.h: attn_row_hash / attn_elem_hash): one full
+    hash per (batch*head, query) row, then a light per-key mix."""
+    rows = np.arange(BH * T, dtype=np.uint64)
+    rowh = _mix32(_mix32(rows ^ np.uint64(seed & 0xFFFFFFFF)) ^ np.uint64(stream & 0xFFFFFFFF))
+    keys = (np.arange(T, dtype=np.uint64) * 0x9E3779B1) & 0xFFFFFFFF
+    x = rowh[:, None] ^ keys[None, :]
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
+    return (x >= thr).reshape(BH, T, T)
+
+
 def dropout_stream(step, layer, site):
     """site: 0 embed, 1 attention probabilities, 2 attn c_proj output, 3 mlp output."""
     return ((step * 64 + layer) * 4 + site) & 0xFFFFFFFF
@@ -173,8 +187,12 @@ class OracleTransformer:
     def _dropout(self, x, p, step, layer, site, training):
         if not training or p <= 0.0:
             return x, None
-        keep = dropout_keep(self.seed, dropout_stream(step, layer, site),
-                            np.arange(x.size, dtype=np.uint64), p).reshape(x.shape)
+        if site == 1:      # attention probabilities [B,H,T,T]
+            keep = dropout_keep_attn(self.seed, dropout_stream(step, layer, site), x.shape[0] * x.shape[1],
+                                     x.shape[2], p).reshape(x.shape)
+        else:
+            keep = dropout_keep(self.seed, dropout_stream(step, layer, site),
+                                np.arange(x.size, dtype=np.uint64), p).reshape(x.shape)
         scale = 1.0 / (1.0 - p)
         m = keep.astype(self.dtype) * scale
         return x * m, m

@@ -59,7 +59,7 @@ TOL = {FP32: 2e-5, BF16: 1.2e-2}
 
 # ------------------------------------------------------------------------------------------ GEMM
 def gemm(lib, dtype, ta, tb, A, B, M, N, K, bias=None, act=0, aux=None, resid=None, out_fp32=False, splitk=1,
-         p_drop=0.0, seed=0, rng=0, C0=None, ldc=None):
+         p_drop=0.0, seed=0, rng=0, C0=None, ldc=None, flags=0):
     ldc = ldc or N
     if C0 is not None:
         Cm = C0
@@ -68,23 +68,38 @@ def gemm(lib, dtype, ta, tb, A, B, M, N, K, bias=None, act=0, aux=None, resid=No
     lda, ldb = A.shape[1], B.shape[1]
     ck(lib, lib.cmp_k_gemm(stream(), dtype, ta, tb, M, N, K, P(A), lda, P(B), ldb, P(Cm), ldc, P(bias), act, P(aux),
                            aux.shape[1] if aux is not None else 0, P(resid), resid.shape[1] if resid is not None else 0,
-                           int(out_fp32), splitk, p_drop, seed, rng))
+                           int(out_fp32), splitk, p_drop, seed, rng, flags))
     torch.cuda.synchronize()
     return Cm
 
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 392, 72), (200, 136, 392), (384, 640, 256)])
-def test_gemm_layouts(lib, dtype, ta, tb, M, N, K):
+@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 392, 72), (200, 136, 392), (384, 640, 256), (1000, 264, 512)])
+def test_gemm_layouts(lib, dtype, ta, tb, M, N, K, flags):
+    """flags=0: fast direct-to-LDS kernel where eligible; flags=2: forces the generic register-staged kernel."""
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
     a = torch.randn(M, K, generator=g)
     b = torch.randn(K, N, generator=g)
     A = dev(a.t().contiguous() if ta else a, dtype)
     B = dev(b.t().contiguous() if tb else b, dtype)
     ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
-    out = gemm(lib, dtype, ta, tb, A, B, M, N, K)
+    out = gemm(lib, dtype, ta, tb, A, B, M, N, K, flags=flags)
     assert rel_err(out, ref) < TOL[dtype]
+
+
+def test_gemm_bf16_ragged_k_zero_padded(lib):
+    """dH = dZ.wte: K = V = 390 with dZ rows zero-padded to 448 (CMP_GEMM_KPAD_ZERO) takes the fast path."""
+    M, N, K, ld = 300, 128, 390, 448
+    g = torch.Generator().manual_seed(1)
+    a = torch.zeros(M, ld); a[:, :K] = torch.randn(M, K, generator=g)
+    A, B = dev(a, BF16), dev(torch.randn(K, N, generator=g), BF16)
+    junk = dev(torch.full((64, N), 1e4), BF16)      # memory right after B must not leak in: range-checked loads
+    ref = A.double()[:, :K] @ B.double()
+    for flags in (1, 2):
+        out = gemm(lib, BF16, 0, 0, A, B, M, N, K, flags=flags)
+        assert rel_err(out, ref) < TOL[BF16]
 
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
@@ -205,7 +220,7 @@ def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
     lse = torch.zeros(B * H * T, device="cuda")
     ck(lib, lib.cmp_k_attn_fwd(stream(), P(qkv), P(o), P(lse), B, T, H, D, 1, dtype, p, 1234, 21))
     torch.cuda.synchronize()
-    keep = O.dropout_keep(1234, 21, np.arange(B * H * T * T, dtype=np.uint64), p) if p > 0 else None
+    keep = O.dropout_keep_attn(1234, 21, B * H, T, p) if p > 0 else None
     x, oref, lseref = attn_ref(qkv, B, T, H, D, keep, p)
     tol = TOL[dtype] * (3 if dtype == BF16 else 1)
     assert rel_err(o, oref.detach().reshape(B * T, E)) < tol

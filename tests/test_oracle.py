@@ -115,6 +115,12 @@ def test_dropout_keep_rate_and_determinism():
     assert abs(k.mean() - 0.9) < 0.01
     k2 = O.dropout_keep(123, O.dropout_stream(1, 2, 3), np.arange(1 << 16, dtype=np.uint64), 0.1)
     assert (k == k2).all()
+    # attention mask: right rate, no row/column structure
+    a = O.dropout_keep_attn(7, O.dropout_stream(0, 1, 1), 8, 256, 0.1)
+    assert abs(a.mean() - 0.9) < 0.005
+    assert np.abs(a.mean(axis=(0, 1)) - 0.9).max() < 0.05 and np.abs(a.mean(axis=(0, 2)) - 0.9).max() < 0.05
+    assert abs(np.corrcoef(a[:, :, :-1].ravel(), a[:, :, 1:].ravel())[0, 1]) < 0.01
+    assert abs(np.corrcoef(a[:, :-1, :].ravel(), a[:, 1:, :].ravel())[0, 1]) < 0.01
 
 
 def test_param_count_matches_survey():
