@@ -39,6 +39,13 @@ template <> struct AT<float> {
 
 template <typename T> using frag_t = typename AT<T>::frag;
 
+// Requiring 2 waves/SIMD caps the kernel at 256 registers, which makes hipcc keep MFMA accumulators in VGPR form;
+// with the 512-register budget of 1 wave/SIMD it parks them in AGPRs and pays a v_accvgpr_read/write pair for
+// every softmax/rescale touch of an accumulator (measured: ~40% of the loop's vector instructions).
+template <typename T, int D> struct Occ {
+    static constexpr int MINW = (std::is_same<T, float>::value && D == 128) ? 1 : 2;
+};
+
 template <typename T, int D> struct Geo {
     static constexpr int DP = D < 32 ? 32 : D;                       // padded head width (zero filled)
     static constexpr int DT = DP / 32;                               // 32-row output tiles along d
@@ -76,6 +83,40 @@ __device__ __forceinline__ void stage_rows(T* img, const T* __restrict__ g, int6
         }
     }
 }
+
+// Software-pipelined staging of a [64 rows][D] tile: load() issues the global loads of the NEXT tile into registers
+// before the current tile's MFMA/softmax work (latency hides under it), store() writes them to the other LDS
+// buffer afterwards -- one barrier per tile.
+template <typename T, int D> struct Stager {
+    static constexpr int VN = AT<T>::VN, DP = Geo<T, D>::DP, S = Geo<T, D>::S, CPR = DP / VN;
+    static constexpr int NC = (64 * CPR + 255) / 256;
+    Vec16<T> r[NC];
+    __device__ __forceinline__ void load(const T* __restrict__ g, int64_t gstride, int row0, int row_end, int tid) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, cc = c % CPR;
+#pragma unroll
+            for (int j = 0; j < VN; j++) r[i].set(j, 0.f);
+            if (c < 64 * CPR && row0 + row < row_end && cc * VN < D) r[i] = ld16(g + (int64_t)(row0 + row) * gstride + cc * VN);
+        }
+    }
+    __device__ __forceinline__ void store(T* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, cc = c % CPR;
+            if (c < 64 * CPR) {
+                if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                    for (int j = 0; j < VN; j++) img[row * S + cc * VN + j] = r[i].get(j);
+                } else {
+                    st16(img + row * S + cc * VN, r[i]);
+                }
+            }
+        }
+    }
+};
 
 // per-lane register fragments of a [32 rows][D] global tile used as the MFMA B operand B[k=d][col=row]
 template <typename T, int D>
@@ -145,7 +186,30 @@ __device__ __forceinline__ f32x16 mma_acc_b(const T* img, int krow0, int dt, con
     return acc;
 }
 
-template <bool EXACT> __device__ __forceinline__ float exp_f(float x) { return EXACT ? expf(x) : __expf(x); }
+#define LOG2E_F 1.4426950408889634f
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float max16(const f32x16& s) {
+    float a = max3(s[0], s[1], s[2]), b = max3(s[3], s[4], s[5]), c = max3(s[6], s[7], s[8]);
+    float d = max3(s[9], s[10], s[11]), e = max3(s[12], s[13], s[14]);
+    return max3(max3(a, b, c), max3(d, e, s[15]), a);
+}
+
+// Dropout keep-test on the 16 values of one 32-key sub-tile with the QUERY on the lane (forward, dQ): the four
+// registers 4*g4..4*g4+3 hold consecutive keys, so they share the xor base and use the four fixed 24-bit multipliers
+// (v_mul_u32_u24 is full rate; v_mul_lo_u32 is quarter rate).  Dropped entries become 0; the 1/(1-p) scale is applied
+// ONCE to the kernel's output instead of per element.
+__device__ __forceinline__ void mask16_qlane(f32x16& v, uint32_t rowh, int k0, int h, uint32_t thr) {
+    const uint32_t gg = ((uint32_t)(k0 >> 2) + (uint32_t)h) * ATTN_G;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+        const uint32_t x = rowh ^ (gg + (uint32_t)(2 * g4) * ATTN_G);
+        v[4 * g4 + 0] = (__umul24(x, ATTN_C0) >= thr) ? v[4 * g4 + 0] : 0.f;
+        v[4 * g4 + 1] = (__umul24(x, ATTN_C1) >= thr) ? v[4 * g4 + 1] : 0.f;
+        v[4 * g4 + 2] = (__umul24(x, ATTN_C2) >= thr) ? v[4 * g4 + 2] : 0.f;
+        v[4 * g4 + 3] = (__umul24(x, ATTN_C3) >= thr) ? v[4 * g4 + 3] : 0.f;
+    }
+}
 
 // store a transposed accumulator tile Y^T[d][row] (d in registers, row on the lane) to out[row][d0 + d]
 template <typename T, int D>
@@ -169,89 +233,157 @@ __device__ __forceinline__ void store_t_tile(T* __restrict__ out, int64_t ostrid
     }
 }
 
+// Causal work balance: query block i needs i+1 key tiles.  A workgroup takes the PAIR (nb-1-x, x) -- heavy one
+// first -- so every workgroup does nb+1 tiles (the middle block of an odd count runs alone).  grid.x = (nb+1)/2.
+__device__ __forceinline__ int pair_block(int ph, int nb, int x) {
+    const int hi = nb - 1 - x;
+    if (ph == 0) return hi;
+    return x < hi ? x : -1;
+}
+
 // =================================================================================================
-// forward.  grid (ceil(T/128), B*H), 256 threads: wave w owns query rows [qb*128 + 32w, +32)
+// forward.  grid ((nb+1)/2, B*H), 256 threads: wave w owns query rows [qb*128 + 32w, +32)
 // =================================================================================================
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
-                                                       float* __restrict__ lse, int Tn, int H, float scale,
-                                                       DropCfg drop) {
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                                          float* __restrict__ lse, int Tn, int H,
+                                                                          float scale, DropCfg drop) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);          // [64][S]
-    T* Vs = Ks + 64 * G::S;                          // [64][S]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    T* Kb = reinterpret_cast<T*>(smem_raw);          // 2 x { K [64][S] | V [64][S] }
+    constexpr int IMG = 64 * G::S;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y / H, hd = blockIdx.y % H;
     const int E = H * D;
     const int64_t rs = 3 * E;                        // row stride of qkv
     const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
     const T* kg = qg + E;
     const T* vg = qg + 2 * E;
-    const int q0w = blockIdx.x * 128 + wave * 32;
-    const int q = q0w + (lane & 31);
-    const bool qvalid = q < Tn;
-    frag_t<T> qf[G::NS];
-    load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
-
-    f32x16 oacc[G::DT];
-#pragma unroll
-    for (int dt = 0; dt < G::DT; dt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
-    const int kv_end = min(Tn, blockIdx.x * 128 + 128);
-    const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
-
-    for (int kt0 = 0; kt0 < kv_end; kt0 += 64) {
-        __syncthreads();
-        stage_rows<T, D>(Ks, kg, rs, kt0, Tn, 64, tid);
-        stage_rows<T, D>(Vs, vg, rs, kt0, Tn, 64, tid);
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
-            const int k0 = kt0 + 32 * sub;
-            if (k0 > q0w + 31 || k0 >= Tn) continue;          // wave-uniform: tile entirely masked
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; r++) s[r] = 0.f;
-            s = mma_rows<T, D>(Ks, 32 * sub, qf, lane, s);
-            float mloc = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int key = k0 + rho(r, h);
-                float v = s[r] * scale;
-                if (key > q || key >= Tn) v = -1e4f;          // w*b - 1e4*(1-b), transformer.py:354
-                s[r] = v;
-                mloc = fmaxf(mloc, v);
-            }
-            mloc = fmaxf(mloc, xhalf(mloc));
-            const float mnew = fmaxf(m, mloc);
-            const float alpha = exp_f<EXACT>(m - mnew);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float p = exp_f<EXACT>(s[r] - mnew);
-                ps += p;
-                if (drop.thr) p = attn_elem_hash(rowh, (uint32_t)(k0 + rho(r, h))) >= drop.thr ? p * drop.scale : 0.f;
-                s[r] = p;
-            }
-            lsum = lsum * alpha + ps;
-            m = mnew;
-#pragma unroll
-            for (int dt = 0; dt < G::DT; dt++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
-                oacc[dt] = mma_acc_b<T, D>(Vs, 32 * sub, dt, s, lane, oacc[dt]);
-            }
-        }
-    }
-    const float ltot = lsum + xhalf(lsum);
-    const float inv = 1.0f / ltot;
     T* og = o + (int64_t)b * Tn * E + hd * D;
+    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const int nb = cdiv(Tn, 128);
+
+    for (int ph = 0; ph < 2; ph++) {
+        const int qb = pair_block(ph, nb, blockIdx.x);
+        if (qb < 0) break;
+        const int q0w = qb * 128 + wave * 32;
+        const int q = q0w + (lane & 31);
+        const bool qvalid = q < Tn;
+        frag_t<T> qf[G::NS];
+        load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
+        f32x16 oacc[G::DT];
 #pragma unroll
-    for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(og, E, q, qvalid, dt, oacc[dt], inv, h);
-    if (qvalid && h == 0) lse[(int64_t)blockIdx.y * Tn + q] = m + logf(ltot);
+        for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
+        float m = -INFINITY, lsum = 0.f;   // running max: scaled domain (parity mode) / raw domain (throughput mode)
+        const int kv_end = min(Tn, qb * 128 + 128);
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
+
+        Stager<T, D> sk, sv;
+        sk.load(kg, rs, 0, Tn, tid);
+        sv.load(vg, rs, 0, Tn, tid);
+        sk.store(Kb, tid);
+        sv.store(Kb + IMG, tid);
+        __syncthreads();
+        for (int kt0 = 0, it = 0; kt0 < kv_end; kt0 += 64, it++) {
+            const T* Ks = Kb + (it & 1) * 2 * IMG;
+            const T* Vs = Ks + IMG;
+            const bool more = kt0 + 64 < kv_end;
+            if (more) {
+                sk.load(kg, rs, kt0 + 64, Tn, tid);
+                sv.load(vg, rs, kt0 + 64, Tn, tid);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const int k0 = kt0 + 32 * sub;
+                if (k0 > q0w + 31 || k0 >= Tn) continue;          // wave-uniform: tile entirely masked
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; r++) s[r] = 0.f;
+                s = mma_rows<T, D>(Ks, 32 * sub, qf, lane, s);
+                if constexpr (EXACT) {
+                    // parity mode: the reference's arithmetic as written (scale, mask to exactly -1e4, exp)
+                    float mloc = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        int key = k0 + rho(r, h);
+                        float v = s[r] * scale;
+                        if (key > q || key >= Tn) v = -1e4f;          // w*b - 1e4*(1-b), transformer.py:354
+                        s[r] = v;
+                        mloc = fmaxf(mloc, v);
+                    }
+                    mloc = fmaxf(mloc, xhalf(mloc));
+                    const float mnew = fmaxf(m, mloc);
+                    const float alpha = expf(m - mnew);
+                    float ps = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float p = expf(s[r] - mnew);
+                        ps += p;
+                        s[r] = p;
+                    }
+                    lsum = lsum * alpha + ps;
+                    m = mnew;
+#pragma unroll
+                    for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+                } else {
+                    // throughput mode: raw scores, the scale folded into ONE fma feeding v_exp_f32 (base 2), mask only
+                    // on tiles touching the diagonal / sequence end, rescale only when some row's max actually grew.
+                    const bool edge = (k0 + 31 > q0w) || (k0 + 32 > Tn);      // wave-uniform
+                    if (edge) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            int key = k0 + rho(r, h);
+                            if (key > q || key >= Tn) s[r] = neg_big;       // == -1e4 after scaling
+                        }
+                    }
+                    float mloc = max16(s);
+                    mloc = fmaxf(mloc, xhalf(mloc));
+                    const float mnew = fmaxf(m, mloc);
+                    if (!__all(mnew == m)) {
+                        const float alpha = fast_exp2((m - mnew) * c2);
+                        lsum *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                            for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+                        m = mnew;
+                    }
+                    const float mc = m * c2;
+                    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        float p0 = fast_exp2(fmaf(s[r], c2, -mc));
+                        float p1 = fast_exp2(fmaf(s[r + 1], c2, -mc));
+                        ps0 += p0;
+                        ps1 += p1;
+                        s[r] = p0;
+                        s[r + 1] = p1;
+                    }
+                    lsum += ps0 + ps1;
+                }
+                if constexpr (DROP) mask16_qlane(s, rowh, k0, h, drop.thr);
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++) oacc[dt] = mma_acc_b<T, D>(Vs, 32 * sub, dt, s, lane, oacc[dt]);
+            }
+            if (more) {
+                T* nbuf = Kb + ((it & 1) ^ 1) * 2 * IMG;
+                sk.store(nbuf, tid);
+                sv.store(nbuf + IMG, tid);
+            }
+            __syncthreads();
+        }
+        const float ltot = lsum + xhalf(lsum);
+        const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(og, E, q, qvalid, dt, oacc[dt], inv, h);
+        if (qvalid && h == 0) lse[(int64_t)blockIdx.y * Tn + q] = (EXACT ? m : m * scale) + logf(ltot);
+    }
 }
 
 // =================================================================================================
@@ -283,17 +415,20 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
 
 // =================================================================================================
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
+// With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
 // =================================================================================================
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
-                                                      const float* __restrict__ lse, const float* __restrict__ delta,
-                                                      T* __restrict__ dqkv, int Tn, int H, float scale, DropCfg drop) {
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                                         const float* __restrict__ lse,
+                                                                         const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                                         int Tn, int H, float scale, DropCfg drop) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);
-    T* Vs = Ks + 64 * G::S;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    T* Kb = reinterpret_cast<T*>(smem_raw);          // 2 x { K | V }
+    constexpr int IMG = 64 * G::S;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y / H, hd = blockIdx.y % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
@@ -301,70 +436,107 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const T* __restrict__ qkv,
     const T* kg = qg + E;
     const T* vg = qg + 2 * E;
     const T* dog = d_o + (int64_t)b * Tn * E + hd * D;
-    const int q0w = blockIdx.x * 128 + wave * 32;
-    const int q = q0w + (lane & 31);
-    const bool qvalid = q < Tn;
-    frag_t<T> qf[G::NS], dof[G::NS];
-    load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
-    load_bfrags<T, D>(dof, dog, E, q, qvalid, h);
-    const float lse_q = qvalid ? lse[(int64_t)blockIdx.y * Tn + q] : 0.f;
-    const float del_q = qvalid ? delta[(int64_t)blockIdx.y * Tn + q] : 0.f;
-    f32x16 dq[G::DT];
-#pragma unroll
-    for (int dt = 0; dt < G::DT; dt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dq[dt][r] = 0.f;
-    const int kv_end = min(Tn, blockIdx.x * 128 + 128);
-    const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
+    T* dqg = dqkv + (int64_t)b * Tn * rs + hd * D;
+    const float c2 = scale * LOG2E_F;
+    const float keep_scale = DROP ? drop.scale : 1.0f;
+    const int nb = cdiv(Tn, 128);
 
-    for (int kt0 = 0; kt0 < kv_end; kt0 += 64) {
+    for (int ph = 0; ph < 2; ph++) {
+        const int qb = pair_block(ph, nb, blockIdx.x);
+        if (qb < 0) break;
+        const int q0w = qb * 128 + wave * 32;
+        const int q = q0w + (lane & 31);
+        const bool qvalid = q < Tn;
+        frag_t<T> qf[G::NS], dof[G::NS];
+        load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
+        load_bfrags<T, D>(dof, dog, E, q, qvalid, h);
+        const float lse_q = qvalid ? lse[(int64_t)blockIdx.y * Tn + q] : 0.f;
+        const float del_q = (qvalid ? delta[(int64_t)blockIdx.y * Tn + q] : 0.f) / keep_scale;
+        const float lse2 = lse_q * LOG2E_F;
+        f32x16 dq[G::DT];
+#pragma unroll
+        for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dq[dt][r] = 0.f;
+        const int kv_end = min(Tn, qb * 128 + 128);
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
+
+        Stager<T, D> sk, sv;
+        sk.load(kg, rs, 0, Tn, tid);
+        sv.load(vg, rs, 0, Tn, tid);
+        sk.store(Kb, tid);
+        sv.store(Kb + IMG, tid);
         __syncthreads();
-        stage_rows<T, D>(Ks, kg, rs, kt0, Tn, 64, tid);
-        stage_rows<T, D>(Vs, vg, rs, kt0, Tn, 64, tid);
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
-            const int k0 = kt0 + 32 * sub;
-            if (k0 > q0w + 31 || k0 >= Tn) continue;
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
-            s = mma_rows<T, D>(Ks, 32 * sub, qf, lane, s);
-            dp = mma_rows<T, D>(Vs, 32 * sub, dof, lane, dp);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                int key = k0 + rho(r, h);
-                bool masked = (key > q) || (key >= Tn) || !qvalid;
-                float p = masked ? 0.f : exp_f<EXACT>(s[r] * scale - lse_q);
-                float dpv = dp[r];
-                if (drop.thr) dpv = attn_elem_hash(rowh, (uint32_t)key) >= drop.thr ? dpv * drop.scale : 0.f;
-                s[r] = p * (dpv - del_q);
+        for (int kt0 = 0, it = 0; kt0 < kv_end; kt0 += 64, it++) {
+            const T* Ks = Kb + (it & 1) * 2 * IMG;
+            const T* Vs = Ks + IMG;
+            const bool more = kt0 + 64 < kv_end;
+            if (more) {
+                sk.load(kg, rs, kt0 + 64, Tn, tid);
+                sv.load(vg, rs, kt0 + 64, Tn, tid);
             }
 #pragma unroll
-            for (int dt = 0; dt < G::DT; dt++) dq[dt] = mma_acc_b<T, D>(Ks, 32 * sub, dt, s, lane, dq[dt]);
-        }
-    }
-    T* dqg = dqkv + (int64_t)b * Tn * rs + hd * D;
+            for (int sub = 0; sub < 2; sub++) {
+                const int k0 = kt0 + 32 * sub;
+                if (k0 > q0w + 31 || k0 >= Tn) continue;
+                f32x16 s, dp;
 #pragma unroll
-    for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale, h);
+                for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+                s = mma_rows<T, D>(Ks, 32 * sub, qf, lane, s);
+                dp = mma_rows<T, D>(Vs, 32 * sub, dof, lane, dp);
+                if constexpr (DROP) mask16_qlane(dp, rowh, k0, h, drop.thr);
+                if constexpr (EXACT) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        int key = k0 + rho(r, h);
+                        bool masked = (key > q) || (key >= Tn) || !qvalid;
+                        float p = masked ? 0.f : expf(s[r] * scale - lse_q);
+                        s[r] = p * (dp[r] - del_q);
+                    }
+                } else {
+                    const bool edge = (k0 + 31 > q0w) || (k0 + 32 > Tn) || (q0w + 32 > Tn);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float p = fast_exp2(fmaf(s[r], c2, -lse2));
+                        if (edge) {
+                            int key = k0 + rho(r, h);
+                            if ((key > q) || (key >= Tn) || !qvalid) p = 0.f;
+                        }
+                        s[r] = p * (dp[r] - del_q);
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++) dq[dt] = mma_acc_b<T, D>(Ks, 32 * sub, dt, s, lane, dq[dt]);
+            }
+            if (more) {
+                T* nbuf = Kb + ((it & 1) ^ 1) * 2 * IMG;
+                sk.store(nbuf, tid);
+                sv.store(nbuf + IMG, tid);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale * keep_scale, h);
+    }
 }
 
 // =================================================================================================
-// dK, dV.  grid (ceil(T/128), B*H): wave w owns keys [kb*128 + 32w, +32); loops over query tiles >= its keys
+// dK, dV.  grid ((nb+1)/2, B*H): wave w owns keys [kb*128 + 32w, +32); loops over the query tiles at or below the
+// diagonal.  Key block j needs nb-j query blocks -> paired (j, nb-1-j) like the forward.
 // =================================================================================================
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
-                                                       const float* __restrict__ lse, const float* __restrict__ delta,
-                                                       T* __restrict__ dqkv, int Tn, int H, float scale, DropCfg drop) {
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                                          const float* __restrict__ lse,
+                                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                                          int Tn, int H, float scale, DropCfg drop) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Qs = reinterpret_cast<T*>(smem_raw);          // [64][S]
-    T* Os = Qs + 64 * G::S;                          // dO [64][S]
-    float* Ls = reinterpret_cast<float*>(Os + 64 * G::S);   // lse [64]
-    float* Dl = Ls + 64;                             // delta [64]
-    uint32_t* Rh = reinterpret_cast<uint32_t*>(Dl + 64);   // dropout row hashes [64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    T* Qb = reinterpret_cast<T*>(smem_raw);          // 2 x { Q [64][S] | dO [64][S] }
+    constexpr int IMG = 64 * G::S;
+    float* Lb = reinterpret_cast<float*>(Qb + 4 * IMG);     // 2 x { lse [64] | delta/f [64] | dropout row hash [64] }
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y / H, hd = blockIdx.y % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
@@ -372,67 +544,123 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv
     const T* kg = qg + E;
     const T* vg = qg + 2 * E;
     const T* dog = d_o + (int64_t)b * Tn * E + hd * D;
-    const int k0w = blockIdx.x * 128 + wave * 32;
-    const int key = k0w + (lane & 31);
-    const bool kvalid = key < Tn;
-    frag_t<T> kf[G::NS], vf[G::NS];
-    load_bfrags<T, D>(kf, kg, rs, key, kvalid, h);
-    load_bfrags<T, D>(vf, vg, rs, key, kvalid, h);
-    f32x16 dk[G::DT], dv[G::DT];
-#pragma unroll
-    for (int dt = 0; dt < G::DT; dt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    for (int qt0 = (blockIdx.x * 128) & ~63; qt0 < Tn; qt0 += 64) {
-        __syncthreads();
-        stage_rows<T, D>(Qs, qg, rs, qt0, Tn, 64, tid);
-        stage_rows<T, D>(Os, dog, E, qt0, Tn, 64, tid);
-        if (tid < 64) {
-            int qq = qt0 + tid;
-            Ls[tid] = qq < Tn ? lse[(int64_t)blockIdx.y * Tn + qq] : 0.f;
-            Dl[tid] = qq < Tn ? delta[(int64_t)blockIdx.y * Tn + qq] : 0.f;
-            Rh[tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + qq));
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
-            const int qb0 = qt0 + 32 * sub;
-            if (qb0 + 31 < k0w || qb0 >= Tn || k0w >= Tn) continue;     // wave-uniform: all (q, key) pairs masked
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
-            s = mma_rows<T, D>(Qs, 32 * sub, kf, lane, s);              // S[q][key]
-            dp = mma_rows<T, D>(Os, 32 * sub, vf, lane, dp);            // dP[q][key]
-            f32x16 pt;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int ql = 32 * sub + rho(r, h);
-                const int qq = qt0 + ql;
-                bool masked = (key > qq) || (qq >= Tn) || !kvalid;
-                float p = masked ? 0.f : exp_f<EXACT>(s[r] * scale - Ls[ql]);
-                float dpv = dp[r];
-                float pd = p;
-                if (drop.thr) {
-                    const bool keep = attn_elem_hash(Rh[ql], (uint32_t)key) >= drop.thr;
-                    dpv = keep ? dpv * drop.scale : 0.f;
-                    pd = keep ? p * drop.scale : 0.f;
-                }
-                pt[r] = pd;                         // dropped probabilities feed dV
-                s[r] = p * (dpv - Dl[ql]);          // dS feeds dK
-            }
-#pragma unroll
-            for (int dt = 0; dt < G::DT; dt++) {
-                dv[dt] = mma_acc_b<T, D>(Os, 32 * sub, dt, pt, lane, dv[dt]);
-                dk[dt] = mma_acc_b<T, D>(Qs, 32 * sub, dt, s, lane, dk[dt]);
-            }
-        }
-    }
     T* dkg = dqkv + (int64_t)b * Tn * rs + E + hd * D;
     T* dvg = dkg + E;
+    const float c2 = scale * LOG2E_F;
+    const float keep_scale = DROP ? drop.scale : 1.0f;
+    const int nb = cdiv(Tn, 128);
+
+    for (int ph = 0; ph < 2; ph++) {
+        // light/heavy are mirrored w.r.t. the forward: key block 0 is the heavy one
+        const int kb = ph == 0 ? (int)blockIdx.x : ((int)blockIdx.x < nb - 1 - (int)blockIdx.x ? nb - 1 - (int)blockIdx.x : -1);
+        if (kb < 0) break;
+        const int k0w = kb * 128 + wave * 32;
+        const int key = k0w + (lane & 31);
+        const bool kvalid = key < Tn;
+        frag_t<T> kf[G::NS], vf[G::NS];
+        load_bfrags<T, D>(kf, kg, rs, key, kvalid, h);
+        load_bfrags<T, D>(vf, vg, rs, key, kvalid, h);
+        const uint32_t kgG = ((uint32_t)key >> 2) * ATTN_G;
+        const uint32_t kC = (key & 3) == 0 ? ATTN_C0 : ((key & 3) == 1 ? ATTN_C1 : ((key & 3) == 2 ? ATTN_C2 : ATTN_C3));
+        f32x16 dk[G::DT], dv[G::DT];
 #pragma unroll
-    for (int dt = 0; dt < G::DT; dt++) {
-        store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale, h);
-        store_t_tile<T, D>(dvg, rs, key, kvalid, dt, dv[dt], 1.0f, h);
+        for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+        Stager<T, D> sq, so;
+        float st_l = 0.f, st_d = 0.f;
+        auto load_rows = [&](int qt) {     // per-row scalars of tile qt: threads 0..63
+            if (tid < 64) {
+                const int qq = qt + tid;
+                st_l = qq < Tn ? lse[(int64_t)blockIdx.y * Tn + qq] * (EXACT ? 1.0f : LOG2E_F) : 0.f;
+                st_d = qq < Tn ? delta[(int64_t)blockIdx.y * Tn + qq] / keep_scale : 0.f;
+            }
+        };
+        auto store_rows = [&](float* dst, int qt) {
+            if (tid < 64) {
+                dst[tid] = st_l;
+                dst[64 + tid] = st_d;
+                reinterpret_cast<uint32_t*>(dst)[128 + tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + qt + tid));
+            }
+        };
+        const int qstart = kb * 128;
+        sq.load(qg, rs, qstart, Tn, tid);
+        so.load(dog, E, qstart, Tn, tid);
+        load_rows(qstart);
+        sq.store(Qb, tid);
+        so.store(Qb + IMG, tid);
+        store_rows(Lb, qstart);
+        __syncthreads();
+        for (int qt0 = qstart, it = 0; qt0 < Tn; qt0 += 64, it++) {
+            const T* Qs = Qb + (it & 1) * 2 * IMG;
+            const T* Os = Qs + IMG;
+            const float* Ls = Lb + (it & 1) * 192;
+            const bool more = qt0 + 64 < Tn;
+            if (more) {
+                sq.load(qg, rs, qt0 + 64, Tn, tid);
+                so.load(dog, E, qt0 + 64, Tn, tid);
+                load_rows(qt0 + 64);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const int qb0 = qt0 + 32 * sub;
+                if (qb0 + 31 < k0w || qb0 >= Tn || k0w >= Tn) continue;     // wave-uniform: all (q, key) pairs masked
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+                s = mma_rows<T, D>(Qs, 32 * sub, kf, lane, s);              // S[q][key]
+                dp = mma_rows<T, D>(Os, 32 * sub, vf, lane, dp);            // dP~[q][key]
+                // row constants of the 16 query rows this lane sees: rows 8g+4h .. +3 are consecutive -> 16-byte reads
+                f32x4 lq[4], dq4[4];
+                __attribute__((ext_vector_type(4))) uint32_t rh4[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int ql = 32 * sub + 8 * g + 4 * h;
+                    lq[g] = *reinterpret_cast<const f32x4*>(Ls + ql);
+                    dq4[g] = *reinterpret_cast<const f32x4*>(Ls + 64 + ql);
+                    if constexpr (DROP) rh4[g] = *reinterpret_cast<const __attribute__((ext_vector_type(4))) uint32_t*>(Ls + 128 + ql);
+                }
+                const bool edge = EXACT || (qb0 < k0w + 32) || (qb0 + 32 > Tn) || (k0w + 32 > Tn);   // wave-uniform
+                f32x16 pt;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float p;
+                    if constexpr (EXACT) p = expf(s[r] * scale - lq[r >> 2][r & 3]);
+                    else p = fast_exp2(fmaf(s[r], c2, -lq[r >> 2][r & 3]));        // lse*log2(e) in this mode
+                    if (edge) {
+                        const int qq = qt0 + 32 * sub + rho(r, h);
+                        if ((key > qq) || (qq >= Tn) || !kvalid) p = 0.f;
+                    }
+                    float dpv = dp[r];
+                    float pd = p;
+                    if constexpr (DROP) {
+                        const bool keep = __umul24(rh4[r >> 2][r & 3] ^ kgG, kC) >= drop.thr;
+                        dpv = keep ? dpv : 0.f;
+                        pd = keep ? p : 0.f;
+                    }
+                    pt[r] = pd;                                   // (dropped) probabilities feed dV
+                    s[r] = p * (dpv - dq4[r >> 2][r & 3]);        // dS/f feeds dK
+                }
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++) {
+                    dv[dt] = mma_acc_b<T, D>(Os, 32 * sub, dt, pt, lane, dv[dt]);
+                    dk[dt] = mma_acc_b<T, D>(Qs, 32 * sub, dt, s, lane, dk[dt]);
+                }
+            }
+            if (more) {
+                T* nbuf = Qb + ((it & 1) ^ 1) * 2 * IMG;
+                sq.store(nbuf, tid);
+                so.store(nbuf + IMG, tid);
+                store_rows(Lb + ((it & 1) ^ 1) * 192, qt0 + 64);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int dt = 0; dt < G::DT; dt++) {
+            store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale * keep_scale, h);
+            store_t_tile<T, D>(dvg, rs, key, kvalid, dt, dv[dt], keep_scale, h);
+        }
     }
 }
 
@@ -441,11 +669,16 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const T* __restrict__ qkv
 // =================================================================================================
 template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
-    size_t smem = 2 * 64 * Geo<T, D>::S * sizeof(T);
-    dim3 grid(cdiv(Tn, 128), B * H);
+    size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
+    if (smem > 65536) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
     const double flops = 2.0 * B * H * (double)Tn * Tn * D;      // QK^T + PV on the unmasked half
     PROF_START(3, s);
-    attn_fwd_kernel<T, D><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
+    if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
+    else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
     PROF_STOP(3, s, flops);
     KERNEL_CHECK();
     return CMP_OK;
@@ -455,16 +688,23 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
                       void* dqkv, int B, int Tn, int H, float scale, DropCfg d) {
     attn_delta_kernel<T><<<(int)std::min<int64_t>(cdiv64((int64_t)B * Tn, 4), 4096), 256, 0, s>>>((const T*)o, (const T*)d_o, delta, B, Tn, H, D);
     KERNEL_CHECK();
-    dim3 grid(cdiv(Tn, 128), B * H);
-    size_t smem = 2 * 64 * Geo<T, D>::S * sizeof(T);
+    dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
+    size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
+    if (smem + 1536 > 65536) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_dq_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_dq_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_dkv_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem + 1536));
+        HIP_CHECK(hipFuncSetAttribute((const void*)attn_dkv_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem + 1536));
+    }
     const double fl = (double)B * H * (double)Tn * Tn * D;        // one product over the unmasked half
     PROF_START(4, s);
-    attn_dq_kernel<T, D><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    if (d.thr) attn_dq_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    else attn_dq_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
     PROF_STOP(4, s, 3.0 * fl);
     KERNEL_CHECK();
     PROF_START(5, s);
-    attn_dkv_kernel<T, D><<<grid, 256, smem + 192 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta,
-                                                                          (T*)dqkv, Tn, H, scale, d);
+    if (d.thr) attn_dkv_kernel<T, D, true><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    else attn_dkv_kernel<T, D, false><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
     PROF_STOP(5, s, 4.0 * fl);
     KERNEL_CHECK();
     return CMP_OK;

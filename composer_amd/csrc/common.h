@@ -84,12 +84,18 @@ static inline uint32_t drop_stream(int64_t step, int layer, int site) {
 __host__ __device__ __forceinline__ uint32_t attn_row_hash(uint32_t seed, uint32_t stream, uint32_t row) {
     return mix32(mix32(row ^ seed) ^ stream);
 }
+#define ATTN_G 0x9E3779B1u
+#define ATTN_C0 0xEBCA6Bu     // 24-bit odd multipliers: v_mul_u32_u24 is a full-rate instruction
+#define ATTN_C1 0xB2AE35u
+#define ATTN_C2 0xD4EB2Fu
+#define ATTN_C3 0x5667B1u
+// keep(row, key) = (((rowhash ^ ((key>>2)*G)) & 0xFFFFFF) * C24[key&3]) mod 2^32 >= thr : per element ONE multiply + compare;
+// the xor base is shared by 4 consecutive keys (statistics checked in tests/test_oracle.py).
 __host__ __device__ __forceinline__ uint32_t attn_elem_hash(uint32_t rowhash, uint32_t key) {
-    uint32_t x = rowhash ^ (key * 0x9E3779B1u);
-    x ^= x >> 16;
-    x *= 0x7FEB352Du;
-    x ^= x >> 15;
-    return x;
+    const uint32_t x = rowhash ^ ((key >> 2) * ATTN_G);
+    const uint32_t k3 = key & 3u;
+    const uint32_t cc = k3 == 0 ? ATTN_C0 : (k3 == 1 ? ATTN_C1 : (k3 == 2 ? ATTN_C2 : ATTN_C3));
+    return (x & 0xFFFFFFu) * cc;
 }
 
 struct DropCfg {

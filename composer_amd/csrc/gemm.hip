@@ -204,7 +204,7 @@ __device__ __forceinline__ bf16x8 g_frag(const char* img, int t16, int ks, int l
 }
 
 template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int64_t lda,
                                                         const bf16_t* __restrict__ B, int64_t ldb, void* C, int ldc,
                                                         Epilogue ep, int ktiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A img | B img]
@@ -343,6 +343,60 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& ep, void* C, int
     }
 }
 
+// 8 consecutive columns of one row (col % 8 == 0); columns >= N of a ragged last chunk are not stored
+__device__ __forceinline__ void epilogue_store8(const Epilogue& ep, void* C, int ldc, int row, int col, int N, f32x4 v0, f32x4 v1) {
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const bool full = col + 8 <= N;
+    if (ep.bias) {
+        if (full) {
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col), b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (col + j < N) v[j] += ep.bias[col + j];
+        }
+    }
+    if (ep.act == 1) {
+        if (ep.aux) {
+            bf16x8 a;
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x8*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col) = a;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = gelu_f<false>(v[j]);
+    } else if (ep.act == 2) {
+        bf16x8 a = *reinterpret_cast<const bf16x8*>((const bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)a[j]);
+    }
+    if (ep.drop.thr) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+    }
+    if (ep.resid) {
+        bf16x8 r = *reinterpret_cast<const bf16x8*>((const bf16_t*)ep.resid + (int64_t)row * ep.ldr + col);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] += (float)r[j];
+    }
+    if (ep.out_fp32) {
+        float* o = (float*)C + (int64_t)row * ldc + col;
+        if (full) {
+            *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (col + j < N) o[j] = v[j];
+        }
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8*>((bf16_t*)C + (int64_t)row * ldc + col) = o;     // ldc is padded to a multiple of 8
+    }
+}
+
 template <bool A_KM, bool B_KM, bool SWAP>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
@@ -410,15 +464,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
         __syncthreads();     // also drains the LDS-DMA of the next tile (vmcnt(0) is emitted with the barrier)
     }
     if (SWAP) {
+        // Epilogue through LDS (the pipeline buffers are free after the loop's last barrier): each wave parks its
+        // 64x64 fp32 tile, 32 rows at a time, in a private [32][68]-float region (b128 writes and reads conflict-free),
+        // then every lane finishes 8 consecutive columns of one row: bias/aux/residual/output are all 16-byte,
+        // row-contiguous accesses (8 lanes = one full 128-B line of bf16).
+        float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
-            if (row < M) {
+        for (int half = 0; half < 2; half++) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-                    if (col < N) epilogue_store4<bf16_t>(ep, C, ldc, row, col, acc[i][j]);
-                }
+            for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<f32x4*>(stg + (ii * 16 + (lane & 15)) * 68 + j * 16 + (lane >> 4) * 4) = acc[half * 2 + ii][j];
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int rl = it * 8 + (lane >> 3);
+                const int row = m0 + wm * 64 + half * 32 + rl;
+                const int col = n0 + wn * 64 + (lane & 7) * 8;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rl * 68 + (lane & 7) * 8);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rl * 68 + (lane & 7) * 8 + 4);
+                if (row < M && col < N) epilogue_store8(ep, C, ldc, row, col, N, v0, v1);
             }
         }
     } else {
@@ -493,8 +558,8 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
         const bool kpad = (K % 64 == 0) || ((flags & 1) && (ta || lda >= (K + 63) / 64 * 64) && (!tb || ldb >= (K + 63) / 64 * 64));
         const bool km_ok = (ta && !tb) || kpad;
         const int64_t a_span = (int64_t)(ta ? K : M) * lda * 2, b_span = (int64_t)(tb ? N : K) * ldb * 2;
-        const bool fast = km_ok && a_span < 0x7FFFFFF0ll && b_span < 0x7FFFFFF0ll && N % 4 == 0 && ldc % 4 == 0 &&
-                          (!aux || ldaux % 4 == 0) && (!resid || ldr % 4 == 0) && !(flags & 2);
+        const bool fast = km_ok && a_span < 0x7FFFFFF0ll && b_span < 0x7FFFFFF0ll && ldc % 8 == 0 && (out_fp32 || N % 8 == 0) &&
+                          (!aux || (ldaux % 8 == 0 && N % 8 == 0)) && (!resid || (ldr % 8 == 0 && N % 8 == 0)) && !(flags & 2);
         PROF_START(cls, s);
         if (fast) {
             const int tiles_n = cdiv(N, G_BN), ntiles = tiles_n * cdiv(M, G_BM);

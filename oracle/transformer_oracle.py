@@ -94,14 +94,13 @@ def dropout_keep(seed, stream, idx, p):
 
 def dropout_keep_attn(seed, stream, BH, T, p):
     """Attention-probability mask [BH, T(query), T(key)] (csrc/common.h: attn_row_hash / attn_elem_hash): one full
-    hash per (batch*head, query) row, then a light per-key mix."""
+    hash per (batch*head, query) row; the 4 keys of a group share the xor base and differ by the multiplier."""
     rows = np.arange(BH * T, dtype=np.uint64)
     rowh = _mix32(_mix32(rows ^ np.uint64(seed & 0xFFFFFFFF)) ^ np.uint64(stream & 0xFFFFFFFF))
-    keys = (np.arange(T, dtype=np.uint64) * 0x9E3779B1) & 0xFFFFFFFF
-    x = rowh[:, None] ^ keys[None, :]
-    x ^= x >> 16
-    x = (x * 0x7FEB352D) & 0xFFFFFFFF
-    x ^= x >> 15
+    keys = np.arange(T, dtype=np.uint64)
+    cq = np.array([0xEBCA6B, 0xB2AE35, 0xD4EB2F, 0x5667B1], dtype=np.uint64)       # 24-bit multipliers
+    x = (rowh[:, None] ^ (((keys >> 2) * 0x9E3779B1) & 0xFFFFFFFF)[None, :]) & 0xFFFFFF
+    x = (x * cq[keys & 3][None, :]) & 0xFFFFFFFF
     thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
     return (x >= thr).reshape(BH, T, T)
 

@@ -86,6 +86,13 @@ def bench_attn():
         print("attn fwd  p=%.1f  %8.1f us  %7.1f TFLOP/s (causal-half flops)" % (p, us, fl / us / 1e6))
         us = timeit(lambda: lib.cmp_k_attn_bwd(st(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, BF16, p, 1, 2))
         print("attn bwd  p=%.1f  %8.1f us  %7.1f TFLOP/s (2.5x fwd flops)" % (p, us, 2.5 * fl / us / 1e6))
+        for cls, nm in ((4, "dq"), (5, "dkv")):
+            lib.cmp_prof_begin(cls)
+            for _ in range(10):
+                lib.cmp_k_attn_bwd(st(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, BF16, p, 1, 2)
+            ms, n, w = C.c_double(), C.c_int64(), C.c_double()
+            lib.cmp_prof_end(C.byref(ms), C.byref(n), C.byref(w))
+            print("    %-4s p=%.1f  %8.1f us  %7.1f TFLOP/s" % (nm, p, 1e3 * ms.value / n.value, w.value / ms.value / 1e9))
 
 
 def bench_ln():
