@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libcomposer_hip.so")
 ROOT = os.path.dirname(HERE)
 SOURCES = ["elementwise.hip", "gemm.hip", "attention.hip", "model.hip", "decode.hip"]
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm", "-I" + os.path.join(ROOT, "include")]
 
 
 def _hipcc():

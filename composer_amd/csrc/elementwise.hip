@@ -63,7 +63,7 @@ __global__ void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __res
 // one wave per row; a lane owns chunks (lane + 64*i) of 16 bytes.
 // =================================================================================================
 #define LN_MAXI 4
-template <typename T>
+template <typename T, int MAXI>
 __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, T* __restrict__ y,
                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int E,
@@ -74,10 +74,10 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
     const int chunks = E / VN;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
         const T* xr = x + (int64_t)row * E;
-        Vec16<T> v[LN_MAXI];
+        Vec16<T> v[MAXI];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXI; i++) {
+        for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
                 v[i] = ld16(xr + c * VN);
@@ -88,7 +88,7 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
         float mu = wave_sum(s) / (float)E;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXI; i++) {
+        for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
 #pragma unroll
@@ -101,7 +101,7 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
         float var = wave_sum(q) / (float)E;
         float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
-        for (int i = 0; i < LN_MAXI; i++) {
+        for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
                 Vec16<T> o;
@@ -122,8 +122,8 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
 
 // dx = resid + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;  partial dgamma/dbeta per workgroup
 // into ws[wg][2][E]; ln_param_reduce_kernel folds them into dgamma/dbeta.
-template <typename T>
-__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int MAXI>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const T* __restrict__ resid,
                                      T* __restrict__ dx, float* __restrict__ ws, int rows, int E) {
@@ -132,9 +132,9 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     const int chunks = E / VN;
-    float dg[LN_MAXI][VN], db[LN_MAXI][VN], gm[LN_MAXI][VN];
+    float dg[MAXI][VN], db[MAXI][VN], gm[MAXI][VN];
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; i++) {
+    for (int i = 0; i < MAXI; i++) {
         int c = lane + 64 * i;
 #pragma unroll
         for (int j = 0; j < VN; j++) {
@@ -145,10 +145,10 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
     }
     for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
         const float mu = mean[row], rs = rstd[row];
-        Vec16<T> vdy[LN_MAXI], vx[LN_MAXI];
+        Vec16<T> vdy[MAXI], vx[MAXI];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXI; i++) {
+        for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
                 vdy[i] = ld16(dy + (int64_t)row * E + c * VN);
@@ -168,7 +168,7 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
         s1 = wave_sum(s1) / (float)E;
         s2 = wave_sum(s2) / (float)E;
 #pragma unroll
-        for (int i = 0; i < LN_MAXI; i++) {
+        for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
                 Vec16<T> o, r;
@@ -188,7 +188,7 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
     // cross-wave reduction of the parameter-gradient partials
     float* sm = ln_smem + (size_t)wave * 2 * E;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; i++) {
+    for (int i = 0; i < MAXI; i++) {
         int c = lane + 64 * i;
         if (c < chunks) {
 #pragma unroll
@@ -453,17 +453,19 @@ extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gam
     if (rows == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = std::min(cdiv(rows, 4), 8192);
+    const int vn = dtype == CMP_BF16 ? 8 : 4;
+    const int maxi = cdiv(E / vn, 64);          // 16-byte chunks per lane: 1 for E <= 512 (bf16) / 256 (fp32)
     PROF_START(6, s);
-    if (dtype == CMP_BF16)
-        layernorm_fwd_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, E, eps);
-    else
-        layernorm_fwd_kernel<float><<<grid, 256, 0, s>>>((const float*)x, gamma, beta, (float*)y, mean, rstd, rows, E, eps);
+#define LN_FWD(TT, MI) layernorm_fwd_kernel<TT, MI><<<grid, 256, 0, s>>>((const TT*)x, gamma, beta, (TT*)y, mean, rstd, rows, E, eps)
+    if (dtype == CMP_BF16) { if (maxi == 1) LN_FWD(bf16_t, 1); else if (maxi == 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4); }
+    else { if (maxi == 1) LN_FWD(float, 1); else if (maxi == 2) LN_FWD(float, 2); else LN_FWD(float, 4); }
+#undef LN_FWD
     PROF_STOP(6, s, (double)rows * (2.0 * E * dtype_size(dtype) + 8.0));
     KERNEL_CHECK();
     return CMP_OK;
 }
 
-static int ln_bwd_grid(int rows) { return std::max(1, std::min(cdiv(rows, 4), 512)); }
+static int ln_bwd_grid(int rows) { return std::max(1, std::min(cdiv(rows, 8), 2048)); }
 
 extern "C" int64_t cmp_k_layernorm_bwd_ws(int rows, int E) { return (int64_t)ln_bwd_grid(rows) * 2 * E * sizeof(float); }
 
@@ -476,12 +478,12 @@ extern "C" int cmp_k_layernorm_bwd(void* stream, const void* dy, const void* x, 
     hipStream_t s = (hipStream_t)stream;
     int grid = ln_bwd_grid(rows);
     size_t smem = (size_t)4 * 2 * E * sizeof(float);
-    if (dtype == CMP_BF16)
-        layernorm_bwd_kernel<bf16_t><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
-                                                              (const bf16_t*)resid, (bf16_t*)dx, (float*)ws, rows, E);
-    else
-        layernorm_bwd_kernel<float><<<grid, 256, smem, s>>>((const float*)dy, (const float*)x, gamma, mean, rstd,
-                                                             (const float*)resid, (float*)dx, (float*)ws, rows, E);
+    const int vn = dtype == CMP_BF16 ? 8 : 4;
+    const int maxi = cdiv(E / vn, 64);
+#define LN_BWD(TT, MI) layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E)
+    if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
+    else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
+#undef LN_BWD
     KERNEL_CHECK();
     ln_param_reduce_kernel<<<dim3(cdiv(2 * E, 256), std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, grid, E);
     KERNEL_CHECK();

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(int M, int N, int K, 
 //   * 1-D grid with a bijective XCD-aware remap: workgroups that share an A row-panel run on one XCD's L2.
 // =================================================================================================
 typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
 
 template <bool KM>
 __device__ __forceinline__ void glds_tile(__amdgpu_buffer_rsrc_t rs, char* img, int ld_bytes, int k0, int wave, int lane) {
@@ -500,6 +501,436 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
     }
 }
 
+// =================================================================================================
+// bf16 large-tile path: 256x256x64 workgroup tile, 8 waves (2 x 4) of 128x64, PERSISTENT workgroups (one per CU).
+//   * 128 FLOP per byte staged into LDS (the 128x128 tile: 64) -- the 128^2 kernel saturates L2->LDS bandwidth at
+//     ~1 PFLOP/s (measured on the K=2048 shapes);
+//   * a workgroup walks its list of (tile, k-split) items; right after an item's last k-step it issues the NEXT
+//     item's first k-slab into stage 0, so that load flies under the epilogue (which parks accumulators in stage 1);
+//   * same LDS images / swizzles / direct-to-LDS staging / range-checked descriptors as the 128^2 fast path.
+// LDS: 2 stages x (A 32 KiB + B 32 KiB) = 128 KiB.
+// =================================================================================================
+#define H_BM 256
+#define H_BN 256
+#define H_IMG (256 * 64 * 2)
+__device__ __forceinline__ int cslow_off512(int k, int c) { return k * 512 + ((c ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1)) << 4); }
+
+template <bool KM>
+__device__ __forceinline__ void glds_tile256(__amdgpu_buffer_rsrc_t rs, char* img, int ld_bytes, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = wave * 4 + i;           // 32 pieces of 1 KiB
+        int voff;
+        if (KM) {
+            const int r = 8 * p + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            voff = r * ld_bytes + (k0 + c * 8) * 2;
+        } else {
+            const int k = 2 * p + (lane >> 5);
+            const int c = (lane & 31) ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1);
+            voff = (k0 + k) * ld_bytes + c * 16;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(img + p * 1024), 16, voff, 0, 0, 0);
+    }
+}
+template <bool KM>
+__device__ __forceinline__ bf16x8 h_frag(const char* img, int t16, int ks, int lane) {
+    if (KM) {
+        int row = t16 * 16 + (lane & 15);
+        int c = ks * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(img + kmaj_off(row, c));
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int k = ks * 32 + 8 * g + q;
+        const int c = t16 * 2 + (p >> 1);
+        const int sub = (p & 1) * 8;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off512(k, c) + sub));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off512(k + 4, c) + sub));
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f[j] = lo[j];
+            f[4 + j] = hi[j];
+        }
+        return f;
+    }
+}
+
+template <bool A_KM, bool B_KM, bool SWAP>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
+                                                               const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
+                                                               Epilogue ep, int ktiles_per_split, int nsplit, int tiles_n,
+                                                               int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A img | B img]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nitems = ntiles * nsplit;
+    const int nk = cdiv(K, G_BK);
+
+    auto item_coords = [&](int item, int& m0, int& n0, int& kt0, int& kt1) {
+        // bijective XCD remap over items: the items one XCD works on are consecutive (shared A row panel in its L2)
+        const int q = nitems >> 3, r = nitems & 7, x = item & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
+        const int tile = lin / nsplit, sp = lin % nsplit;
+        m0 = (tile / tiles_n) * H_BM;
+        n0 = (tile % tiles_n) * H_BN;
+        kt0 = sp * ktiles_per_split;
+        kt1 = min(nk, kt0 + ktiles_per_split);
+    };
+    auto make_rsrc = [&](const bf16_t* P, bool km, int64_t rows, int ld, int t0) {
+        const bf16_t* base = km ? P + (int64_t)t0 * ld : P + t0;
+        const int64_t bytes = (km ? (rows - t0) * ld : rows * ld - t0) * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)min(bytes, (int64_t)0x7FFFFFF0), 0x00020000);
+    };
+
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    int m0, n0, kt0, kt1;
+    item_coords(item, m0, n0, kt0, kt1);
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
+    if (kt0 < kt1) {
+        glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
+        glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
+    }
+    while (true) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();      // stage 0 of this item has landed (vmcnt(0) rides on the barrier); previous epilogue left stage 1
+        for (int kt = kt0; kt < kt1; kt++) {
+            const int st = (kt - kt0) & 1;
+            const char* ia = smem + st * 2 * H_IMG;
+            const char* ib = ia + H_IMG;
+            if (kt + 1 < kt1) {
+                char* na = smem + (st ^ 1) * 2 * H_IMG;
+                glds_tile256<A_KM>(ra, na, lda * 2, (kt + 1) * G_BK, wave, lane);
+                glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, (kt + 1) * G_BK, wave, lane);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 fb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fb[j] = h_frag<B_KM>(ib, wn * 4 + j, ks, lane);
+#pragma unroll
+                for (int ih = 0; ih < 2; ih++) {
+                    bf16x8 fa[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) fa[i] = h_frag<A_KM>(ia, wm * 8 + ih * 4 + i, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (SWAP) acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih * 4 + i][j], 0, 0, 0);
+                            else acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[ih * 4 + i][j], 0, 0, 0);
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        // next item's first k-slab goes to stage 0 while this item's epilogue runs out of stage 1
+        const int cm0 = m0, cn0 = n0;
+        const int next = item + gridDim.x;
+        const bool has_next = next < nitems;
+        if (has_next) {
+            item_coords(next, m0, n0, kt0, kt1);
+            ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
+            rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
+            if (kt0 < kt1) {
+                glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
+                glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
+            }
+        }
+        if (SWAP) {
+            float* stg = reinterpret_cast<float*>(smem + 2 * H_IMG) + wave * (16 * 68);   // stage 1: [16][68] floats per wave
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<f32x4*>(stg + (lane & 15) * 68 + j * 16 + (lane >> 4) * 4) = acc[i][j];
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int rl = it * 8 + (lane >> 3);
+                    const int row = cm0 + wm * 128 + i * 16 + rl;
+                    const int col = cn0 + wn * 64 + (lane & 7) * 8;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rl * 68 + (lane & 7) * 8);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rl * 68 + (lane & 7) * 8 + 4);
+                    if (row < M && col < N) epilogue_store8(ep, C, ldc, row, col, N, v0, v1);
+                }
+            }
+        } else {
+            // split-K items: plain f32 atomics, 16 consecutive floats per row per wave-instruction
+            float* Cf = (float*)C;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int col = cn0 + wn * 64 + j * 16 + (lane & 15);
+                    const int row0 = cm0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+                    if (col < N) {
+                        if (row0 + 0 < M) atomicAdd(Cf + (int64_t)(row0 + 0) * ldc + col, acc[i][j][0]);
+                        if (row0 + 1 < M) atomicAdd(Cf + (int64_t)(row0 + 1) * ldc + col, acc[i][j][1]);
+                        if (row0 + 2 < M) atomicAdd(Cf + (int64_t)(row0 + 2) * ldc + col, acc[i][j][2]);
+                        if (row0 + 3 < M) atomicAdd(Cf + (int64_t)(row0 + 3) * ldc + col, acc[i][j][3]);
+                    }
+                }
+        }
+        if (!has_next) break;
+        item = next;
+    }
+}
+
+// =================================================================================================
+// bf16 deep-pipeline path ("p4"): the 256x256 persistent kernel above is latency-bound -- only ONE 64 KiB stage is in
+// flight per CU while L2->LDS needs ~100 KiB in flight to stream at its per-CU rate.  Same tile and wave layout, but
+//   * 4 LDS stages of BK = 32 (A 16 KiB + B 16 KiB each), up to 3 stages in flight;
+//   * per k-step: counted s_waitcnt vmcnt(8/4/0) (never a full drain in steady state) -> raw s_barrier -> issue the
+//     stage 3 steps ahead into the buffer that was computed LAST step (free once every wave passed this barrier)
+//     -> 32 MFMAs per wave from the current stage;
+//   * the next item's first three stages are issued before the epilogue, which parks accumulators in stage 3.
+// =================================================================================================
+#define P_BK 32
+#define P_IMG (256 * 32 * 2)      // 16 KiB per operand image
+#define P_STAGE (2 * P_IMG)
+
+// K-major image [256 rows][32 k] (64-byte rows): chunk c (0..3) of row r; the xor table makes the ds_read_b128 lane
+// groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (rows 0-3,12-15 with chunk g, rows 4-11 with chunk g+1) conflict-free
+__device__ __forceinline__ int p_sw(int r) {   // {0,2,3,1}[(r>>2)&3]
+    const int q = (r >> 2) & 3;
+    return (0x78 >> (2 * q)) & 3;              // 0b01_11_10_00
+}
+__device__ __forceinline__ int pk_off(int r, int c) { return r * 64 + ((c ^ p_sw(r)) << 4); }
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor words (stride 0, range-checked): {base[31:0], base[47:32], num_records, flags}
+__device__ __forceinline__ v4i32 make_srd(const void* base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    v4i32 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xFFFFu));
+    d[2] = __builtin_amdgcn_readfirstlane((int)min(bytes, (int64_t)0x7FFFFFF0));
+    d[3] = 0x00020000;
+    return d;
+}
+// One 1-KiB LDS-DMA piece issued from inline asm, so hipcc's wait-count pass does not see a pending LDS write (it
+// would put s_waitcnt vmcnt(0) in front of the next ds_read and drain the pipeline).  M0 (LDS base) is written in
+// the same statement that reads it; completion is tracked by hand with counted s_waitcnt vmcnt(N).
+__device__ __forceinline__ void dma16(v4i32 srd, uint32_t lds_addr, int voff) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(srd)
+                 : "memory", "m0");
+}
+
+template <bool KM>
+__device__ __forceinline__ void p_glds(v4i32 rs, uint32_t img_lds, int ld_bytes, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int p = wave * 2 + i;           // 16 pieces of 1 KiB per image
+        int voff;
+        if (KM) {
+            const int r = 16 * p + (lane >> 2);
+            const int c = (lane & 3) ^ p_sw(r);
+            voff = r * ld_bytes + (k0 + c * 8) * 2;
+        } else {
+            const int k = 2 * p + (lane >> 5);
+            const int c = (lane & 31) ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1);
+            voff = (k0 + k) * ld_bytes + c * 16;
+        }
+        dma16(rs, img_lds + p * 1024, voff);
+    }
+}
+template <bool KM>
+__device__ __forceinline__ bf16x8 p_frag(const char* img, int t16, int lane) {
+    if (KM) {
+        return *reinterpret_cast<const bf16x8*>(img + pk_off(t16 * 16 + (lane & 15), lane >> 4));
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int k = 8 * g + q;
+        const int c = t16 * 2 + (p >> 1);
+        const int sub = (p & 1) * 8;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off512(k, c) + sub));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off512(k + 4, c) + sub));
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f[j] = lo[j];
+            f[4 + j] = hi[j];
+        }
+        return f;
+    }
+}
+
+template <bool A_KM, bool B_KM, bool SWAP>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_p4_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
+                                                              const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
+                                                              Epilogue ep, int ksteps_per_split, int nsplit, int tiles_n,
+                                                              int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 stages x [A img | B img]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nitems = ntiles * nsplit;
+    const int nk = cdiv(K, P_BK);
+
+    auto item_coords = [&](int item, int& m0, int& n0, int& kt0, int& kt1) {
+        const int q = nitems >> 3, r = nitems & 7, x = item & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
+        const int tile = lin / nsplit, sp = lin % nsplit;
+        m0 = (tile / tiles_n) * H_BM;
+        n0 = (tile % tiles_n) * H_BN;
+        kt0 = sp * ksteps_per_split;
+        kt1 = min(nk, kt0 + ksteps_per_split);
+    };
+    auto make_rsrc = [&](const bf16_t* P, bool km, int64_t rows, int ld, int t0) {
+        const bf16_t* base = km ? P + (int64_t)t0 * ld : P + t0;
+        const int64_t bytes = (km ? (rows - t0) * ld : rows * ld - t0) * 2;
+        return make_srd(base, bytes);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;     // LDS byte address of the staging area
+
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    int m0, n0, kt0, kt1;
+    item_coords(item, m0, n0, kt0, kt1);
+    v4i32 ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
+    v4i32 rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
+    auto issue = [&](int kt, int buf) {
+        p_glds<A_KM>(ra, lds0 + buf * P_STAGE, lda * 2, kt * P_BK, wave, lane);
+        p_glds<B_KM>(rb, lds0 + buf * P_STAGE + P_IMG, ldb * 2, kt * P_BK, wave, lane);
+    };
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (kt0 + i < kt1) issue(kt0 + i, i);
+
+    while (true) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int n = kt1 - kt0;
+        for (int t = 0; t < n; t++) {
+            // stages t+1, t+2 (4 DMA instructions per wave each) may stay in flight; stage t must have landed
+            const int younger = min(n - t - 1, 2);
+            if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 3 < n) issue(kt0 + t + 3, (t + 3) & 3);     // buffer of step t-1: every wave is past it now
+            const char* ia = smem + (t & 3) * P_STAGE;
+            const char* ib = ia + P_IMG;
+            // fragments one A-tile ahead of the MFMAs that use them: the LDS latency of fa[i+1] hides under the 4 MFMAs of fa[i]
+            bf16x8 fb[4], fa[8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[j] = p_frag<B_KM>(ib, wn * 4 + j, lane);
+            fa[0] = p_frag<A_KM>(ia, wm * 8, lane);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i < 7) fa[i + 1] = p_frag<A_KM>(ia, wm * 8 + i + 1, lane);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, A_KM ? 1 : 2, 0);    // DS_READ of the next A fragment
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);               // 4 MFMA
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave has finished reading the stages of this item
+        const int cm0 = m0, cn0 = n0;
+        const int next = item + gridDim.x;
+        const bool has_next = next < nitems;
+        if (has_next) {
+            item_coords(next, m0, n0, kt0, kt1);
+            ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
+            rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if (kt0 + i < kt1) issue(kt0 + i, i);              // buffers 0..2; the epilogue owns buffer 3
+        }
+        if (SWAP) {
+            // per wave [16 rows][64 floats] = 4 KiB in stage 3, 16-byte chunks xor-swizzled by the row
+            float* stg = reinterpret_cast<float*>(smem + 3 * P_STAGE) + wave * (16 * 64);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int r = lane & 15, c = j * 4 + (lane >> 4);
+                    *reinterpret_cast<f32x4*>(stg + r * 64 + ((c ^ r) << 2)) = acc[i][j];
+                }
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int rl = it * 8 + (lane >> 3);
+                    const int row = cm0 + wm * 128 + i * 16 + rl;
+                    const int col = cn0 + wn * 64 + (lane & 7) * 8;
+                    const int c0 = (lane & 7) * 2;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rl * 64 + ((c0 ^ rl) << 2));
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rl * 64 + (((c0 + 1) ^ rl) << 2));
+                    if (row < M && col < N) epilogue_store8(ep, C, ldc, row, col, N, v0, v1);
+                }
+            }
+        } else {
+            float* Cf = (float*)C;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int col = cn0 + wn * 64 + j * 16 + (lane & 15);
+                    const int row0 = cm0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+                    if (col < N) {
+                        if (row0 + 0 < M) atomicAdd(Cf + (int64_t)(row0 + 0) * ldc + col, acc[i][j][0]);
+                        if (row0 + 1 < M) atomicAdd(Cf + (int64_t)(row0 + 1) * ldc + col, acc[i][j][1]);
+                        if (row0 + 2 < M) atomicAdd(Cf + (int64_t)(row0 + 2) * ldc + col, acc[i][j][2]);
+                        if (row0 + 3 < M) atomicAdd(Cf + (int64_t)(row0 + 3) * ldc + col, acc[i][j][3]);
+                    }
+                }
+        }
+        if (!has_next) break;
+        item = next;
+        // the epilogue's stores/atomics sit in the same vmcnt queue behind the three prefetched stages: drain them
+        // so that the counted waits of the next item see only its own DMA (costs <= one store latency per item)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // after this drain stages 0..2 have landed as well; the first wait of the next item is then a no-op.
+    }
+}
+
+template <bool A_KM, bool B_KM>
+static void launch_p4(hipStream_t s, int grid, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
+                      void* C, int ldc, const Epilogue& ep, int per, int nsplit, int tiles_n, int ntiles) {
+    static bool attr_set = false;
+    const size_t smem = 4 * P_STAGE;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    if (swap)
+        gemm_bf16_p4_kernel<A_KM, B_KM, true><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+    else
+        gemm_bf16_p4_kernel<A_KM, B_KM, false><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+}
+
+template <bool A_KM, bool B_KM>
+static void launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
+                       void* C, int ldc, const Epilogue& ep, int per, int nsplit, int tiles_n, int ntiles) {
+    static bool attr_set = false;
+    const size_t smem = 4 * H_IMG;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    if (swap)
+        gemm_bf16_256_kernel<A_KM, B_KM, true><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+    else
+        gemm_bf16_256_kernel<A_KM, B_KM, false><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+}
+
 template <bool A_KM, bool B_KM>
 static void launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M, int N, int K, const bf16_t* a, int lda,
                         const bf16_t* b, int ldb, void* C, int ldc, const Epilogue& ep, int per, int tiles_n, int ntiles) {
@@ -545,6 +976,7 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
         CMP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm(bf16): leading dimensions must be multiples of 8 (lda=%d ldb=%d)", lda, ldb);
         CMP_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)Bm & 15) == 0, "gemm(bf16): operands must be 16-byte aligned");
         int nk = cdiv(K, G_BK);
+        const int splitk_req = splitk;
         splitk = std::max(1, std::min(splitk, nk));
         int per = cdiv(nk, splitk);
         dim3 grid(cdiv(N, G_BN), cdiv(M, G_BM), cdiv(nk, per));
@@ -561,7 +993,30 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
         const bool fast = km_ok && a_span < 0x7FFFFFF0ll && b_span < 0x7FFFFFF0ll && ldc % 8 == 0 && (out_fp32 || N % 8 == 0) &&
                           (!aux || (ldaux % 8 == 0 && N % 8 == 0)) && (!resid || (ldr % 8 == 0 && N % 8 == 0)) && !(flags & 2);
         PROF_START(cls, s);
-        if (fast) {
+        const bool big = fast && !(flags & 4) && ((flags & (8 | 16)) || ((int64_t)M * N >= 512ll * 512));
+        if (big && !(flags & 8) && K % 32 == 0 || (big && (flags & 16))) {
+            // deep-pipeline kernel: split granularity is a 32-deep k-step
+            const int nk32 = cdiv(K, P_BK);
+            const int want = std::max(1, std::min(splitk_req, nk32));
+            const int per32 = cdiv(nk32, want);
+            const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, H_BM);
+            const int nsplit = cdiv(nk32, per32);
+            const int g1 = std::min(ntiles * nsplit, 256);
+            const bool swap = !ep.atomic;
+            if (!ta && !tb) launch_p4<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
+            else if (!ta && tb) launch_p4<true, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
+            else if (ta && !tb) launch_p4<false, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
+            else launch_p4<false, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
+        } else if (big) {
+            const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, H_BM);
+            const int nsplit = cdiv(nk, per);
+            const int g1 = std::min(ntiles * nsplit, 256);
+            const bool swap = !ep.atomic;
+            if (!ta && !tb) launch_256<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+            else if (!ta && tb) launch_256<true, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+            else if (ta && !tb) launch_256<false, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+            else launch_256<false, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+        } else if (fast) {
             const int tiles_n = cdiv(N, G_BN), ntiles = tiles_n * cdiv(M, G_BM);
             dim3 g1(ntiles, cdiv(nk, per));
             const bool swap = !ep.atomic;

@@ -75,10 +75,10 @@ def gemm(lib, dtype, ta, tb, A, B, M, N, K, bias=None, act=0, aux=None, resid=No
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("flags", [0, 2])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 392, 72), (200, 136, 392), (384, 640, 256), (1000, 264, 512)])
+@pytest.mark.parametrize("flags", [0, 2, 4, 8, 16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 392, 72), (200, 136, 392), (384, 640, 256), (1000, 264, 512), (2104, 520, 192)])
 def test_gemm_layouts(lib, dtype, ta, tb, M, N, K, flags):
-    """flags=0: fast direct-to-LDS kernel where eligible; flags=2: forces the generic register-staged kernel."""
+    """flags=0: automatic choice; 2: generic register-staged kernel; 4: 128x128 direct-to-LDS; 8: persistent 256x256."""
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
     a = torch.randn(M, K, generator=g)
     b = torch.randn(K, N, generator=g)
@@ -116,9 +116,13 @@ def test_gemm_identity_asymmetric(lib, dtype):
     assert torch.equal(out.float().cpu(), B.float().cpu().t())
 
 
-@pytest.mark.parametrize("dtype", [FP32, BF16])
-def test_gemm_epilogues(lib, dtype):
+@pytest.mark.parametrize("dtype,flags", [(FP32, 0), (BF16, 0), (BF16, 4), (BF16, 8), (BF16, 16)])
+def test_gemm_epilogues(lib, dtype, flags):
     M, N, K = 136, 264, 128
+    _gemm = globals()["gemm"]
+    def gemm(*a, **k):          # every call of this test uses the selected kernel
+        k.setdefault("flags", flags)
+        return _gemm(*a, **k)
     g = torch.Generator().manual_seed(5)
     A, B = dev(torch.randn(M, K, generator=g), dtype), dev(torch.randn(K, N, generator=g) * 0.2, dtype)
     bias = dev(torch.randn(N, generator=g))
@@ -149,7 +153,8 @@ def test_gemm_epilogues(lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
-def test_gemm_wgrad_shape_large_k(lib, dtype):
+@pytest.mark.parametrize("flags", [4, 8, 16])
+def test_gemm_wgrad_shape_large_k(lib, dtype, flags):
     """wgrad: contraction over tokens (K=4096) with split-K atomics; ragged output (V=390 rows)."""
     M, N, K = 390, 128, 4096
     g = torch.Generator().manual_seed(11)
@@ -157,7 +162,7 @@ def test_gemm_wgrad_shape_large_k(lib, dtype):
     At[:, 390:] = 0
     B = dev(torch.randn(K, N, generator=g) * 0.1, dtype)
     C0 = torch.zeros(M, N, device="cuda", dtype=torch.float32)
-    out = gemm(lib, dtype, 1, 0, At, B, M, N, K, out_fp32=True, splitk=8, C0=C0)
+    out = gemm(lib, dtype, 1, 0, At, B, M, N, K, out_fp32=True, splitk=8, C0=C0, flags=flags)
     ref = At.double()[:, :390].t() @ B.double()
     assert rel_err(out, ref) < TOL[dtype]
 

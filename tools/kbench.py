@@ -12,6 +12,7 @@ from composer_amd import _lib
 
 lib = _lib.load()
 BF16 = 1
+GFLAGS = 0
 M, E, H, D, T, B = 32768, 512, 8, 64, 1024, 32
 
 
@@ -49,7 +50,7 @@ def gemm_case(name, ta, tb, m, n, k, splitk=1, out_fp32=False, bias=False, act=0
     rs = rnd(m, n) if resid else None
     def run():
         rc = lib.cmp_k_gemm(st(), BF16, ta, tb, m, n, k, P(A), A.shape[1], P(Bm), Bm.shape[1], P(Cm), n, P(bi), act, P(aux),
-                            n if act else 0, P(rs), n if resid else 0, int(out_fp32), splitk, 0.0, 0, 0, flags)
+                            n if act else 0, P(rs), n if resid else 0, int(out_fp32), splitk, 0.0, 0, 0, flags | GFLAGS)
         assert rc == 0, lib.cmp_last_error()
     us = timeit(run)
     print("%-34s M=%6d N=%5d K=%6d splitk=%2d  %8.1f us  %7.1f TFLOP/s" % (name, m, n, k, splitk, us, 2.0 * m * n * k / us / 1e6))
@@ -113,6 +114,7 @@ def bench_ln():
 
 
 if __name__ == "__main__":
+    GFLAGS = int(os.environ.get("KBENCH_GEMM_FLAGS", "0"))
     what = sys.argv[1:] or ["gemm", "attn", "ln"]
     _lib.require_gpu()
     torch.zeros(1, device="cuda")
