@@ -725,11 +725,13 @@ __device__ __forceinline__ void dma16(v4i32 srd, uint32_t lds_addr, int voff) {
                  : "memory", "m0");
 }
 
+// PIECES 1-KiB pieces of one image, issued by this wave: pieces [first, first+count)
 template <bool KM>
-__device__ __forceinline__ void p_glds(v4i32 rs, uint32_t img_lds, int ld_bytes, int k0, int wave, int lane) {
+__device__ __forceinline__ void p_glds(v4i32 rs, uint32_t img_lds, int ld_bytes, int k0, int first, int count, int lane) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int p = wave * 2 + i;           // 16 pieces of 1 KiB per image
+    for (int i = 0; i < 4; i++) {
+        if (i >= count) break;
+        const int p = first + i;
         int voff;
         if (KM) {
             const int r = 16 * p + (lane >> 2);
@@ -743,7 +745,8 @@ __device__ __forceinline__ void p_glds(v4i32 rs, uint32_t img_lds, int ld_bytes,
         dma16(rs, img_lds + p * 1024, voff);
     }
 }
-template <bool KM>
+template <int ROWB> __device__ __forceinline__ int cslow_offw(int k, int c) { return k * ROWB + ((c ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1)) << 4); }
+template <bool KM, int ROWB = 512>
 __device__ __forceinline__ bf16x8 p_frag(const char* img, int t16, int lane) {
     if (KM) {
         return *reinterpret_cast<const bf16x8*>(img + pk_off(t16 * 16 + (lane & 15), lane >> 4));
@@ -752,8 +755,8 @@ __device__ __forceinline__ bf16x8 p_frag(const char* img, int t16, int lane) {
         const int k = 8 * g + q;
         const int c = t16 * 2 + (p >> 1);
         const int sub = (p & 1) * 8;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off512(k, c) + sub));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_off512(k + 4, c) + sub));
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_offw<ROWB>(k, c) + sub));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + cslow_offw<ROWB>(k + 4, c) + sub));
         bf16x8 f;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -764,12 +767,20 @@ __device__ __forceinline__ bf16x8 p_frag(const char* img, int t16, int lane) {
     }
 }
 
-template <bool A_KM, bool B_KM, bool SWAP>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_p4_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
-                                                              const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
-                                                              Epilogue ep, int ksteps_per_split, int nsplit, int tiles_n,
-                                                              int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 stages x [A img | B img]
+// NWM: wave rows (1: 128x256 tile, 4 waves, 2 workgroups per CU; 2: 256x256 tile, 8 waves, 1 per CU).  NST: LDS stages.
+template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST>
+__global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
+                                                                    const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
+                                                                    Epilogue ep, int ksteps_per_split, int nsplit, int tiles_n,
+                                                                    int ntiles) {
+    constexpr int BM = 128 * NWM;
+    constexpr int A_IMG = BM * P_BK * 2, B_IMG = 256 * P_BK * 2, STAGE = A_IMG + B_IMG;
+    constexpr int A_ROWB = BM * 2;                    // row bytes of a contraction-slow A image
+    constexpr int A_PIECES = A_IMG / 1024, NWAVES = 4 * NWM;
+    constexpr int A_PER = A_PIECES / NWAVES, B_PER = 16 / NWAVES;          // pieces per wave: 2 and 4 (NWM=1) / 2 (NWM=2)
+    constexpr int DPS = A_PER + B_PER;                // DMA instructions per wave per stage
+    constexpr int AHEAD = NST - 1;                    // stages issued ahead at the top of an item
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST stages x [A img | B img]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -780,7 +791,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p4_kernel(int M, int N, int 
         const int q = nitems >> 3, r = nitems & 7, x = item & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
         const int tile = lin / nsplit, sp = lin % nsplit;
-        m0 = (tile / tiles_n) * H_BM;
+        m0 = (tile / tiles_n) * BM;
         n0 = (tile % tiles_n) * H_BN;
         kt0 = sp * ksteps_per_split;
         kt1 = min(nk, kt0 + ksteps_per_split);
@@ -799,11 +810,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p4_kernel(int M, int N, int 
     v4i32 ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
     v4i32 rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
     auto issue = [&](int kt, int buf) {
-        p_glds<A_KM>(ra, lds0 + buf * P_STAGE, lda * 2, kt * P_BK, wave, lane);
-        p_glds<B_KM>(rb, lds0 + buf * P_STAGE + P_IMG, ldb * 2, kt * P_BK, wave, lane);
+        // A image: K-major pieces are 16 rows x 64 B; contraction-slow pieces are (1024 / A_ROWB) k-rows
+        if constexpr (A_KM) {
+            p_glds<true>(ra, lds0 + buf * STAGE, lda * 2, kt * P_BK, wave * A_PER, A_PER, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PER; i++) {
+                const int p = wave * A_PER + i;
+                constexpr int KPP = 1024 / A_ROWB;            // k-rows per piece: 4 (BM=128) / 2 (BM=256)
+                constexpr int CPR = A_ROWB / 16;              // 16-byte chunks per row
+                const int k = KPP * p + lane / CPR;
+                const int c = (lane % CPR) ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1);
+                dma16(ra, lds0 + buf * STAGE + p * 1024, (kt * P_BK + k) * lda * 2 + c * 16);
+            }
+        }
+        p_glds<B_KM>(rb, lds0 + buf * STAGE + A_IMG, ldb * 2, kt * P_BK, wave * B_PER, B_PER, lane);
     };
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < AHEAD; i++)
         if (kt0 + i < kt1) issue(kt0 + i, i);
 
     while (true) {
@@ -813,32 +837,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p4_kernel(int M, int N, int 
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int n = kt1 - kt0;
-        for (int t = 0; t < n; t++) {
-            // stages t+1, t+2 (4 DMA instructions per wave each) may stay in flight; stage t must have landed
-            const int younger = min(n - t - 1, 2);
-            if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // Software pipeline ACROSS the barrier: the wait+barrier that publishes stage t+1 sits inside stage t's 32
+        // MFMAs and stage t+1's B fragments + first A fragment are read right after it, under the remaining MFMAs.
+        bf16x8 fb[4], fa0;
+        auto wait_younger = [&](int y) {        // y stages (DPS instructions each) may remain in flight
+            if (y >= 2 && AHEAD >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
+            else if (y >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        if (n > 0) {
+            wait_younger(min(n, AHEAD) - 1);
             __builtin_amdgcn_s_barrier();
-            if (t + 3 < n) issue(kt0 + t + 3, (t + 3) & 3);     // buffer of step t-1: every wave is past it now
-            const char* ia = smem + (t & 3) * P_STAGE;
-            const char* ib = ia + P_IMG;
-            // fragments one A-tile ahead of the MFMAs that use them: the LDS latency of fa[i+1] hides under the 4 MFMAs of fa[i]
-            bf16x8 fb[4], fa[8];
 #pragma unroll
-            for (int j = 0; j < 4; j++) fb[j] = p_frag<B_KM>(ib, wn * 4 + j, lane);
-            fa[0] = p_frag<A_KM>(ia, wm * 8, lane);
+            for (int j = 0; j < 4; j++) fb[j] = p_frag<B_KM, 512>(smem + A_IMG, wn * 4 + j, lane);
+            fa0 = p_frag<A_KM, A_ROWB>(smem, wm * 8, lane);
+        }
+        // Stagger (8-wave tile only): waves w and w+4 share a SIMD; waves 0-3 take the stage barrier after MFMA group
+        // 3, waves 4-7 before group 0 (same barrier count) so the partners run half a stage apart.  With NWM == 1 the
+        // SIMD partner belongs to the other, independent workgroup.
+        auto run_stage = [&](int t, auto BAR) {
+            constexpr int bar_at = decltype(BAR)::value;     // barrier after this MFMA group (-1: before group 0)
+            const char* ia = smem + (t % NST) * STAGE;
+            const char* nia = smem + ((t + 1) % NST) * STAGE;
+            bf16x8 fa[8], fbn[4], fa0n;
+            fa[0] = fa0;
+            auto sync_point = [&]() {
+                // stage t+1 must have landed; stages t+2 .. t+AHEAD-1 may still fly.  Past this barrier every wave has
+                // finished stage t-1, so its buffer takes stage t+AHEAD.
+                wait_younger(min(n - t - 2, AHEAD - 2));
+                __builtin_amdgcn_s_barrier();
+                if (t + AHEAD < n) issue(kt0 + t + AHEAD, (t + AHEAD) % NST);
+                if (t + 1 < n) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fbn[j] = p_frag<B_KM, 512>(nia + A_IMG, wn * 4 + j, lane);
+                    fa0n = p_frag<A_KM, A_ROWB>(nia, wm * 8, lane);
+                }
+            };
+            if constexpr (bar_at < 0) sync_point();
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                if (i < 7) fa[i + 1] = p_frag<A_KM>(ia, wm * 8 + i + 1, lane);
+                if (i < 7) fa[i + 1] = p_frag<A_KM, A_ROWB>(ia, wm * 8 + i + 1, lane);
+                if (i == bar_at) sync_point();
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, A_KM ? 1 : 2, 0);    // DS_READ of the next A fragment
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);               // 4 MFMA
             }
+            if (t + 1 < n) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) fb[j] = fbn[j];
+                fa0 = fa0n;
+            }
+        };
+        if (NWM == 1 || wave < 4) {
+            for (int t = 0; t < n; t++) run_stage(t, std::integral_constant<int, 3>());
+        } else {
+            for (int t = 0; t < n; t++) run_stage(t, std::integral_constant<int, -1>());
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave has finished reading the stages of this item
@@ -850,12 +905,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p4_kernel(int M, int N, int 
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
 #pragma unroll
-            for (int i = 0; i < 3; i++)
-                if (kt0 + i < kt1) issue(kt0 + i, i);              // buffers 0..2; the epilogue owns buffer 3
+            for (int i = 0; i < AHEAD; i++)
+                if (kt0 + i < kt1) issue(kt0 + i, i);              // the epilogue owns the B image of the last stage
         }
         if (SWAP) {
-            // per wave [16 rows][64 floats] = 4 KiB in stage 3, 16-byte chunks xor-swizzled by the row
-            float* stg = reinterpret_cast<float*>(smem + 3 * P_STAGE) + wave * (16 * 64);
+            // per wave [16 rows][64 floats] = 4 KiB, 16-byte chunks xor-swizzled by the row
+            float* stg = reinterpret_cast<float*>(smem + (NST - 1) * STAGE + A_IMG) + wave * (16 * 64);
+            static_assert(NWAVES * 4096 <= B_IMG + (NWM == 2 ? A_IMG : 0), "epilogue staging must fit the last stage");
+            if (NWM == 2) stg = reinterpret_cast<float*>(smem + (NST - 1) * STAGE) + wave * (16 * 64);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
 #pragma unroll
@@ -892,27 +949,35 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_p4_kernel(int M, int N, int 
         }
         if (!has_next) break;
         item = next;
-        // the epilogue's stores/atomics sit in the same vmcnt queue behind the three prefetched stages: drain them
-        // so that the counted waits of the next item see only its own DMA (costs <= one store latency per item)
+        // the epilogue's stores/atomics sit in the same vmcnt queue behind the prefetched stages: drain them so the
+        // counted waits of the next item see only its own DMA (the other workgroup on the CU keeps the pipes busy)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        // after this drain stages 0..2 have landed as well; the first wait of the next item is then a no-op.
     }
 }
 
-template <bool A_KM, bool B_KM>
-static void launch_p4(hipStream_t s, int grid, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
-                      void* C, int ldc, const Epilogue& ep, int per, int nsplit, int tiles_n, int ntiles) {
+template <bool A_KM, bool B_KM, int NWM, int NST>
+static void launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
+                          void* C, int ldc, const Epilogue& ep, int per, int nsplit) {
     static bool attr_set = false;
-    const size_t smem = 4 * P_STAGE;
+    constexpr int BM = 128 * NWM;
+    const size_t smem = (size_t)NST * (BM * P_BK * 2 + 256 * P_BK * 2);
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
+    const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, BM);
+    const int grid = std::min(ntiles * nsplit, NWM == 1 ? 512 : 256);
     if (swap)
-        gemm_bf16_p4_kernel<A_KM, B_KM, true><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+        gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
     else
-        gemm_bf16_p4_kernel<A_KM, B_KM, false><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+        gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+}
+template <bool A_KM, bool B_KM>
+static void launch_p4(hipStream_t s, int cfg, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
+                      void* C, int ldc, const Epilogue& ep, int per, int nsplit) {
+    if (cfg == 1) launch_p4_cfg<A_KM, B_KM, 1, 3>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit);
+    else launch_p4_cfg<A_KM, B_KM, 2, 4>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit);
 }
 
 template <bool A_KM, bool B_KM>
@@ -994,19 +1059,22 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
                           (!aux || (ldaux % 8 == 0 && N % 8 == 0)) && (!resid || (ldr % 8 == 0 && N % 8 == 0)) && !(flags & 2);
         PROF_START(cls, s);
         const bool big = fast && !(flags & 4) && ((flags & (8 | 16)) || ((int64_t)M * N >= 512ll * 512));
-        if (big && !(flags & 8) && K % 32 == 0 || (big && (flags & 16))) {
-            // deep-pipeline kernel: split granularity is a 32-deep k-step
+        // measured at the C2 shapes (tools/kbench.py): both-K-contiguous (dgrad) is fastest on the 2-stage BK=64 kernel
+        // (its DMA pieces are whole 128-byte lines); forward and wgrad on the 4-stage BK=32 deep pipeline.
+        const bool prefer_p4 = !(!ta && tb);
+        if ((big && !(flags & 8) && K % 32 == 0 && prefer_p4) || (big && (flags & 16))) {
+            // deep-pipeline kernels: split granularity is a 32-deep k-step.  cfg 1: 128x256 tiles, 2 workgroups per CU
+            // (one's epilogue/store drain overlaps the other's main loop); cfg 2: 256x256, 1 per CU.
             const int nk32 = cdiv(K, P_BK);
             const int want = std::max(1, std::min(splitk_req, nk32));
             const int per32 = cdiv(nk32, want);
-            const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, H_BM);
             const int nsplit = cdiv(nk32, per32);
-            const int g1 = std::min(ntiles * nsplit, 256);
+            const int cfg = (flags & 32) ? 1 : 2;
             const bool swap = !ep.atomic;
-            if (!ta && !tb) launch_p4<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
-            else if (!ta && tb) launch_p4<true, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
-            else if (ta && !tb) launch_p4<false, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
-            else launch_p4<false, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit, tiles_n, ntiles);
+            if (!ta && !tb) launch_p4<true, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
+            else if (!ta && tb) launch_p4<true, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
+            else if (ta && !tb) launch_p4<false, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
+            else launch_p4<false, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
         } else if (big) {
             const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, H_BM);
             const int nsplit = cdiv(nk, per);

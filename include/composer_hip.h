@@ -158,7 +158,8 @@ int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
 #define CMP_GEMM_GENERIC 2
 #define CMP_GEMM_TILE128 4      /* tests/bench: force the 128x128 direct-to-LDS kernel */
 #define CMP_GEMM_TILE256 8      /* tests/bench: force the persistent 256x256 2-stage kernel */
-#define CMP_GEMM_P4 16          /* tests/bench: force the persistent 256x256 4-stage (BK=32) kernel */
+#define CMP_GEMM_P4 16          /* tests/bench: force the persistent deep-pipeline (BK=32) kernel */
+#define CMP_GEMM_P4_128 32      /* with CMP_GEMM_P4: 128x256 tile / 4 waves / 3 stages / 2 workgroups per CU instead of 256x256 / 8 waves / 4 stages */
 int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype);
 /* causal attention on qkv [B,T,3E] (head-merged, transformer.py:417): o [B,T,E], lse fp32 [B,H,T] */
 int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D,

@@ -75,7 +75,7 @@ def gemm(lib, dtype, ta, tb, A, B, M, N, K, bias=None, act=0, aux=None, resid=No
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("flags", [0, 2, 4, 8, 16])
+@pytest.mark.parametrize("flags", [0, 2, 4, 8, 16, 48])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 392, 72), (200, 136, 392), (384, 640, 256), (1000, 264, 512), (2104, 520, 192)])
 def test_gemm_layouts(lib, dtype, ta, tb, M, N, K, flags):
     """flags=0: automatic choice; 2: generic register-staged kernel; 4: 128x128 direct-to-LDS; 8: persistent 256x256."""
@@ -116,7 +116,7 @@ def test_gemm_identity_asymmetric(lib, dtype):
     assert torch.equal(out.float().cpu(), B.float().cpu().t())
 
 
-@pytest.mark.parametrize("dtype,flags", [(FP32, 0), (BF16, 0), (BF16, 4), (BF16, 8), (BF16, 16)])
+@pytest.mark.parametrize("dtype,flags", [(FP32, 0), (BF16, 0), (BF16, 4), (BF16, 8), (BF16, 16), (BF16, 48)])
 def test_gemm_epilogues(lib, dtype, flags):
     M, N, K = 136, 264, 128
     _gemm = globals()["gemm"]
@@ -153,7 +153,7 @@ def test_gemm_epilogues(lib, dtype, flags):
 
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
-@pytest.mark.parametrize("flags", [4, 8, 16])
+@pytest.mark.parametrize("flags", [4, 8, 16, 48])
 def test_gemm_wgrad_shape_large_k(lib, dtype, flags):
     """wgrad: contraction over tokens (K=4096) with split-K atomics; ragged output (V=390 rows)."""
     M, N, K = 390, 128, 4096
