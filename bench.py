@@ -30,9 +30,9 @@ LR = 1e-3
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 KERNEL_CLASSES = {
-    0: ("gemm_bf16_kernel<A[M,K],B[K,N]> (forward Conv1D/c_fc/c_proj)", "mfma"),
-    1: ("gemm_bf16_kernel<B stored [N,K]> (dgrad)", "mfma"),
-    2: ("gemm_bf16_kernel<A stored [K,M]> (wgrad, split-K)", "mfma"),
+    0: ("gemm_bf16_p4_kernel<A[M,K],B[K,N]> (forward Conv1D: c_attn/c_proj/c_fc/mlp c_proj, tied logits)", "mfma"),
+    1: ("gemm_bf16_256_kernel<B stored [N,K]> (dgrad)", "mfma"),
+    2: ("gemm_bf16_p4_kernel<A stored [K,M]> (wgrad, split-K slabs)", "mfma"),
     3: ("attn_fwd_kernel<bf16,64>", "mfma"),
     4: ("attn_dq_kernel<bf16,64>", "mfma"),
     5: ("attn_dkv_kernel<bf16,64>", "mfma"),
@@ -75,6 +75,22 @@ def cpu_baseline(seconds_budget=25.0):
                       % (n, Bc, T)}
 
 
+def decode_bench(device):
+    """BASELINE config 5: generate 1024 tokens at temperature 1.0 from a 10-id prompt, KV cache + hipGraph per-token
+    step, same 6L/8H/d512 model with window 2048 (prompt + length must fit the wpe table)."""
+    from composer_amd.transformer import Transformer
+    m = Transformer(V, E, 2048, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="fp32", seed=0,
+                    max_batch=1, max_seq=64, device=device)
+    prompt = np.random.default_rng(0).integers(0, V, 10)
+    m.generate(prompt, 32, temperature=1.0, mode="kv", seed=1)               # warm-up
+    t0 = time.perf_counter()
+    m.generate(prompt, 1024, temperature=1.0, mode="kv", seed=1)
+    dt = time.perf_counter() - t0
+    m.close()
+    return {"metric": "decode tokens/sec (generate len=1024, temp=1.0, batch 1, KV cache + hipGraph)",
+            "value": 1024 / dt, "unit": "tokens/s", "us_per_token": 1e6 * dt / 1024, "dtype": "f32"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="sequences per GPU")
     ap.add_argument("--roofline-kernel", type=int, default=0, help="kernel class timed live (see KERNEL_CLASSES)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1)
     args = ap.parse_args()
 
@@ -99,7 +116,8 @@ def main():
     from composer_amd.transformer import Transformer
     from composer_amd import _lib
 
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)     # bootstrap + timing only; gradients go over RCCL
     torch.cuda.set_device(local_rank)
@@ -109,7 +127,7 @@ def main():
     model = Transformer(V, E, W, L, H, attention_dropout_rate=args.dropout, residual_dropout_rate=args.dropout,
                         dtype="bf16", seed=1000 + rank, max_batch=Bq, max_seq=T, device=local_rank)
     model.initialize_parameters(0)                  # identical replicas
-    if world > 1:
+    if world > 1 or under_launcher:      # a 1-rank launch exercises the same RCCL path (buckets, side stream, 1/N scale)
         uid = [Transformer.new_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         model.init_data_parallel(rank, world, uid[0])
@@ -129,7 +147,7 @@ def main():
     def fence():
         model.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     for i in range(args.warmup):
@@ -142,13 +160,13 @@ def main():
         step(args.warmup + i)
     model.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
     ms, n_launch, work = C.c_double(), C.c_int64(), C.c_double()
     lib.cmp_prof_end(C.byref(ms), C.byref(n_launch), C.byref(work))
     loss, acc = model.last_metrics()
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -188,9 +206,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     model.close()
-    if world > 1:
+    if rank == 0:
+        if world == 1 and not args.no_decode:
+            out["decode"] = decode_bench(local_rank)
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

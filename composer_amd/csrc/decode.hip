@@ -108,29 +108,50 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return s;
 }
 
-// y[n] = act( LN?(x) . Wt[n,:] + bias[n] ) + resid[n];   16 columns per workgroup (4 waves x 4 columns)
-#define GV_CPW 4
-template <int ACT, bool LN_IN>
+// y[n] = act( IN(x) . Wt[n,:] + bias[n] ) + resid[n].  One WAVE per output column (4 columns per workgroup): the
+// column's K weights are one contiguous row of the transposed matrix, read 16 bytes per lane with every load of the row
+// in flight at once (K <= 64*4*GV_MAXI).  IN: 0 plain copy, 1 LayerNorm (every workgroup recomputes the row statistics of
+// the 2-8 KiB input: cheaper than another launch), 2 combine of the split-key attention partials.
+#define GV_MAXI 12
+#define ATT_SPLITS 4
+template <int ACT, int IN>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, float eps,
                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ y,
-                                                       float* __restrict__ u_out, int K, int N) {
+                                                       float* __restrict__ u_out, int K, int N, int D) {
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [K] + 8
     float* red = xs + K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (LN_IN) {
+    if (IN == 1) {
         float s = 0.f;
         for (int k = tid; k < K; k += 256) s += x[k];
         float mu = block_sum(s, red) / (float)K;
         float q = 0.f;
-        for (int k = tid; k < K; k += 256) { float d = x[k] - mu; q += d * d; }
+        for (int k = tid; k < K; k += 256) { float dd = x[k] - mu; q += dd * dd; }
         float var = block_sum(q, red) / (float)K;
         float rs = 1.0f / sqrtf(var + eps);
         for (int k = tid; k < K; k += 256) {
             float v = (x[k] - mu) * rs * ln_g[k] + ln_b[k];
             xs[k] = v;
             if (u_out && blockIdx.x == 0) u_out[k] = v;
+        }
+    } else if (IN == 2) {
+        // x: attention partials [H][ATT_SPLITS][D+2] = {o[D] (unnormalised), running max, sum}; K = H*D
+        for (int k = tid; k < K; k += 256) {
+            const int h = k / D, dd = k % D;
+            const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < ATT_SPLITS; s++) mx = fmaxf(mx, p[s * (D + 2) + D]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int s = 0; s < ATT_SPLITS; s++) {
+                const float w = expf(p[s * (D + 2) + D] - mx);       // exp(-inf) = 0 for empty splits
+                num += w * p[s * (D + 2) + dd];
+                den += w * p[s * (D + 2) + D + 1];
+            }
+            xs[k] = num / den;
         }
     } else {
         for (int k = tid; k < K; k += 256) {
@@ -140,65 +161,94 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    const int n0 = (blockIdx.x * 4 + wave) * GV_CPW;
-    float acc[GV_CPW];
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const float* wr = Wt + (int64_t)n * K;
+    f32x4 wv[GV_MAXI];
 #pragma unroll
-    for (int c = 0; c < GV_CPW; c++) acc[c] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-        f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
+    for (int i = 0; i < GV_MAXI; i++) {
+        const int k = (lane + 64 * i) * 4;
+        wv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(wr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < GV_CPW; c++) {
-            int n = n0 + c;
-            if (n < N) {
-                f32x4 wv = *reinterpret_cast<const f32x4*>(Wt + (int64_t)n * K + k);
-                acc[c] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
-            }
+    for (int i = 0; i < GV_MAXI; i++) {
+        const int k = (lane + 64 * i) * 4;
+        if (k < K) {
+            f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
+            acc += xv[0] * wv[i][0] + xv[1] * wv[i][1] + xv[2] * wv[i][2] + xv[3] * wv[i][3];
         }
     }
-#pragma unroll
-    for (int c = 0; c < GV_CPW; c++) {
-        float v = wave_sum(acc[c]);
-        int n = n0 + c;
-        if (lane == 0 && n < N) {
-            if (bias) v += bias[n];
-            if (ACT == 1) v = gelu_f<true>(v);
-            if (resid) v += resid[n];
-            y[n] = v;
-        }
+    float v = wave_sum(acc);
+    if (lane == 0) {
+        if (bias) v += bias[n];
+        if (ACT == 1) v = gelu_f<true>(v);
+        if (resid) v += resid[n];
+        y[n] = v;
     }
 }
 
-// one workgroup per head: append this token's k,v to the cache at st->pos, then softmax(q.K^T * scale).V
+// Split-key single-query attention: grid (H, ATT_SPLITS).  Workgroup (h, s) owns keys [s*chunk, (s+1)*chunk) of head h
+// (chunk = W/ATT_SPLITS); the one that owns position `pos` appends this token's k,v to the cache.  Scores: 16 lanes
+// cooperate on one key (16-byte coalesced reads of the [W][D] cache rows, D <= 64... 128 via two passes), 4 keys per
+// wave-instruction.  Output: unnormalised o[D], max, sum per (h, s); the next kernel (c_proj GEMV, IN=2) combines them.
 __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
-                                                       float* __restrict__ vc, float* __restrict__ att,
+                                                       float* __restrict__ vc, float* __restrict__ part,
                                                        const DecState* __restrict__ st, int E, int D, int W, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // q[D] | red[8] | scores[W] | part[256]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // q[D] | red[8] | scores[cap] | opart[256]
+    const int cap = (W + ATT_SPLITS - 1) / ATT_SPLITS + 4;
     float* qs = sm;
     float* red = sm + D;
     float* sc = red + 8;
-    const int tid = threadIdx.x, h = blockIdx.x;
+    float* opart = sc + cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x, sp = blockIdx.y;
     const int pos = st->pos;
+    // the pos+1 live keys are split evenly (multiples of 4) over the ATT_SPLITS workgroups of this head
+    const int chunk = ((pos + 1 + ATT_SPLITS - 1) / ATT_SPLITS + 3) & ~3;
+    const int j0 = sp * chunk, j1 = min(pos + 1, j0 + chunk);       // keys [j0, j1) of this split (may be empty)
     float* kh = kc + (int64_t)h * W * D;
     float* vh = vc + (int64_t)h * W * D;
+    float* out = part + ((size_t)h * ATT_SPLITS + sp) * (D + 2);
     if (tid < D) {
         qs[tid] = qkv[h * D + tid];
-        kh[(int64_t)pos * D + tid] = qkv[E + h * D + tid];
-        vh[(int64_t)pos * D + tid] = qkv[2 * E + h * D + tid];
+        if (pos >= j0 && pos < j1) {
+            kh[(int64_t)pos * D + tid] = qkv[E + h * D + tid];
+            vh[(int64_t)pos * D + tid] = qkv[2 * E + h * D + tid];
+        }
     }
     __threadfence_block();
     __syncthreads();
-    const int nk = pos + 1;
+    const int nk = j1 - j0;
+    if (nk <= 0) {
+        if (tid < D) out[tid] = 0.f;
+        if (tid == 0) { out[D] = -INFINITY; out[D + 1] = 0.f; }
+        return;
+    }
+    // scores: LPK lanes per key, each lane owns 4 consecutive d; 8 keys in flight per lane group
+    const int LPK = D / 4;                       // 4, 8, 16 or 32 lanes per key
+    const int kpw = 64 / LPK;                    // keys per wave-instruction
+    const int c = lane % LPK, kk = lane / LPK;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + 4 * c);
     float mx = -INFINITY;
-    for (int j = tid; j < nk; j += 256) {
-        const float* kr = kh + (int64_t)j * D;
-        float a = 0.f;
-        for (int d = 0; d < D; d += 4) {
-            f32x4 kv = *reinterpret_cast<const f32x4*>(kr + d);
-            a += qs[d] * kv[0] + qs[d + 1] * kv[1] + qs[d + 2] * kv[2] + qs[d + 3] * kv[3];
+    const int stride = 4 * kpw;
+    for (int jb = wave * kpw + kk; jb < nk; jb += 8 * stride) {
+        f32x4 kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * stride;
+            kv[u] = (j < nk) ? *reinterpret_cast<const f32x4*>(kh + (int64_t)(j0 + j) * D + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        a *= scale;
-        sc[j] = a;
-        mx = fmaxf(mx, a);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * stride;
+            float a = qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3];
+            for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o);
+            a *= scale;
+            if (j < nk) {
+                if (c == 0) sc[j] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
     }
     mx = block_max(mx, red);
     float s = 0.f;
@@ -210,17 +260,29 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     s = block_sum(s, red);
     __syncthreads();
     const int groups = 256 / D;
-    const int g = tid / D, d = tid % D;
+    const int g = tid / D, dd = tid % D;
     float o = 0.f;
-    for (int j = g; j < nk; j += groups) o += sc[j] * vh[(int64_t)j * D + d];
-    float* part = sc + W;
-    part[tid] = o;
+    for (int jb = g; jb < nk; jb += 8 * groups) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * groups;
+            vv[u] = (j < nk) ? vh[(int64_t)(j0 + j) * D + dd] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * groups;
+            if (j < nk) o += sc[j] * vv[u];
+        }
+    }
+    opart[tid] = o;
     __syncthreads();
     if (tid < D) {
         float t = 0.f;
-        for (int gg = 0; gg < groups; gg++) t += part[gg * D + tid];
-        att[h * D + tid] = t / s;
+        for (int gg = 0; gg < groups; gg++) t += opart[gg * D + tid];
+        out[tid] = t;
     }
+    if (tid == 0) { out[D] = mx; out[D + 1] = s; }
 }
 
 // choose the next id from logits[V]; record it; build the next input embedding x = wte[id] + wpe[pos']
@@ -275,17 +337,15 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict
 }
 
 // -------------------------------------------------------------------------------------------------
-static int launch_gemv(hipStream_t s, int act, bool ln_in, const float* x, const float* g, const float* b, float eps,
-                       const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N) {
-    int grid = cdiv(N, 4 * GV_CPW);
+static int launch_gemv(hipStream_t s, int act, int in_mode, const float* x, const float* g, const float* b, float eps,
+                       const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D) {
+    CMP_REQUIRE(K % 4 == 0 && K <= 256 * GV_MAXI, "decode gemv: K=%d unsupported (max %d)", K, 256 * GV_MAXI);
+    int grid = cdiv(N, 4);
     size_t smem = (size_t)(K + 8) * 4;
-    if (act == 1) {
-        if (ln_in) dec_gemv_kernel<1, true><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
-        else dec_gemv_kernel<1, false><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
-    } else {
-        if (ln_in) dec_gemv_kernel<0, true><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
-        else dec_gemv_kernel<0, false><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N);
-    }
+#define GV(A, I) dec_gemv_kernel<A, I><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D)
+    if (act == 1) { if (in_mode == 1) GV(1, 1); else if (in_mode == 2) GV(1, 2); else GV(1, 0); }
+    else { if (in_mode == 1) GV(0, 1); else if (in_mode == 2) GV(0, 2); else GV(0, 0); }
+#undef GV
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -300,18 +360,18 @@ static int enqueue_token_step(cmp_model* m, DecodeState* d) {
     for (int i = 0; i < L; i++) {
         const LayerOff& o = m->lo[i];
         const DecLayerW& w = d->lw[i];
-        CHECK_RC(launch_gemv(s, 0, ln, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr, d->qkv,
-                             d->u, E, 3 * E));
-        size_t smem = (size_t)(m->D + 8 + m->W + 256) * 4;
-        dec_attn_kernel<<<m->H, 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, E, m->D, m->W, scale);
+        CHECK_RC(launch_gemv(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
+                             d->qkv, d->u, E, 3 * E, m->D));
+        size_t smem = (size_t)(m->D + 8 + (m->W + ATT_SPLITS - 1) / ATT_SPLITS + 4 + 256) * 4;
+        dec_attn_kernel<<<dim3(m->H, ATT_SPLITS), 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, E, m->D, m->W, scale);
         KERNEL_CHECK();
-        CHECK_RC(launch_gemv(s, 0, false, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, E, E));
-        CHECK_RC(launch_gemv(s, 1, ln, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
-                             nullptr, E, 4 * E));
-        CHECK_RC(launch_gemv(s, 0, false, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E));
+        CHECK_RC(launch_gemv(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, E, E, m->D));
+        CHECK_RC(launch_gemv(s, 1, ln ? 1 : 0, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
+                             nullptr, E, 4 * E, m->D));
+        CHECK_RC(launch_gemv(s, 0, 0, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E, m->D));
     }
-    CHECK_RC(launch_gemv(s, 0, true, d->x, m->P + m->off_lnf_g, m->P + m->off_lnf_b, eps, m->P + m->off_wte, nullptr, nullptr,
-                         d->logits, nullptr, E, m->V));
+    CHECK_RC(launch_gemv(s, 0, 1, d->x, m->P + m->off_lnf_g, m->P + m->off_lnf_b, eps, m->P + m->off_wte, nullptr, nullptr,
+                         d->logits, nullptr, E, m->V, m->D));
     dec_sample_kernel<<<1, 256, 0, s>>>(d->logits, 0, m->V, d->temperature, (unsigned)d->seed, d->st, d->ids, m->P + m->off_wte,
                                         m->P + m->off_wpe, d->x, E, 0);
     KERNEL_CHECK();
@@ -339,7 +399,7 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     CHECK_RC(dalloc(d, &d->x, (size_t)E * 4));
     CHECK_RC(dalloc(d, &d->u, (size_t)E * 4));
     CHECK_RC(dalloc(d, &d->qkv, (size_t)3 * E * 4));
-    CHECK_RC(dalloc(d, &d->att, (size_t)E * 4));
+    CHECK_RC(dalloc(d, &d->att, (size_t)m->H * ATT_SPLITS * (m->D + 2) * 4));     // split-key attention partials
     CHECK_RC(dalloc(d, &d->r, (size_t)E * 4));
     CHECK_RC(dalloc(d, &d->g, (size_t)4 * E * 4));
     CHECK_RC(dalloc(d, &d->logits, (size_t)m->ldz * 4));

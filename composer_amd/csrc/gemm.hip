@@ -774,7 +774,7 @@ template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST>
 __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                     const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
                                                                     Epilogue ep, int ksteps_per_split, int nsplit, int tiles_n,
-                                                                    int ntiles) {
+                                                                    int ntiles, int64_t slab_stride) {
     constexpr int BM = 128 * NWM;
     constexpr int A_IMG = BM * P_BK * 2, B_IMG = 256 * P_BK * 2, STAGE = A_IMG + B_IMG;
     constexpr int A_ROWB = BM * 2;                    // row bytes of a contraction-slow A image
@@ -789,6 +789,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
     const int nitems = ntiles * nsplit;
     const int nk = cdiv(K, P_BK);
 
+    int cur_split = 0;
     auto item_coords = [&](int item, int& m0, int& n0, int& kt0, int& kt1) {
         const int q = nitems >> 3, r = nitems & 7, x = item & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
@@ -797,6 +798,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         n0 = (tile % tiles_n) * H_BN;
         kt0 = sp * ksteps_per_split;
         kt1 = min(nk, kt0 + ksteps_per_split);
+        cur_split = sp;
     };
     auto make_rsrc = [&](const bf16_t* P, bool km, int64_t rows, int ld, int t0) {
         const bf16_t* base = km ? P + (int64_t)t0 * ld : P + t0;
@@ -900,6 +902,9 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave has finished reading the stages of this item
         const int cm0 = m0, cn0 = n0;
+        // split-K with a slab workspace: every split writes its own fp32 partial tile with the ordinary full-line
+        // epilogue (plain stores run ~4-5x the f32-atomic rate and the sum is reproducible); gemm_slab_reduce folds them
+        void* Cit = slab_stride ? (void*)((float*)C + (int64_t)cur_split * slab_stride) : C;
         const int next = item + gridDim.x;
         const bool has_next = next < nitems;
         if (has_next) {
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                     const int c0 = (lane & 7) * 2;
                     f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rl * 64 + ((c0 ^ rl) << 2));
                     f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rl * 64 + (((c0 + 1) ^ rl) << 2));
-                    if (row < M && col < N) epilogue_store8(ep, C, ldc, row, col, N, v0, v1);
+                    if (row < M && col < N) epilogue_store8(ep, Cit, ldc, row, col, N, v0, v1);
                 }
             }
         } else {
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
 
 template <bool A_KM, bool B_KM, int NWM, int NST>
 static void launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
-                          void* C, int ldc, const Epilogue& ep, int per, int nsplit) {
+                          void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride) {
     static bool attr_set = false;
     constexpr int BM = 128 * NWM;
     const size_t smem = (size_t)NST * (BM * P_BK * 2 + 256 * P_BK * 2);
@@ -971,15 +976,32 @@ static void launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
     const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, BM);
     const int grid = std::min(ntiles * nsplit, NWM == 1 ? 512 : 256);
     if (swap)
-        gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+        gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, slab_stride);
     else
-        gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+        gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, (int64_t)0);
 }
 template <bool A_KM, bool B_KM>
 static void launch_p4(hipStream_t s, int cfg, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
-                      void* C, int ldc, const Epilogue& ep, int per, int nsplit) {
-    if (cfg == 1) launch_p4_cfg<A_KM, B_KM, 1, 3>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit);
-    else launch_p4_cfg<A_KM, B_KM, 2, 4>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit);
+                      void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride) {
+    if (cfg == 1) launch_p4_cfg<A_KM, B_KM, 1, 3>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, slab_stride);
+    else launch_p4_cfg<A_KM, B_KM, 2, 4>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, slab_stride);
+}
+
+// C[i] += sum_s slab[s][i]  (fixed order: reproducible); 16 bytes per lane
+__global__ void gemm_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t n4, int64_t stride4, int nsplit) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 a = reinterpret_cast<f32x4*>(C)[i];
+        for (int sp = 0; sp < nsplit; sp++) a += reinterpret_cast<const f32x4*>(slab)[sp * stride4 + i];
+        reinterpret_cast<f32x4*>(C)[i] = a;
+    }
+}
+static float* g_slab_ws = nullptr;       // split-K workspace registered by the model (cmp_gemm_set_workspace)
+static size_t g_slab_bytes = 0;
+extern "C" int cmp_gemm_set_workspace(void* ws, int64_t bytes) {
+    g_slab_ws = (float*)ws;
+    g_slab_bytes = ws ? (size_t)bytes : 0;
+    return CMP_OK;
 }
 
 template <bool A_KM, bool B_KM>
@@ -1073,11 +1095,22 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
             const int per32 = cdiv(nk32, want);
             const int nsplit = cdiv(nk32, per32);
             const int cfg = (flags & 32) ? 1 : 2;
-            const bool swap = !ep.atomic;
-            if (!ta && !tb) launch_p4<true, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
-            else if (!ta && tb) launch_p4<true, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
-            else if (ta && !tb) launch_p4<false, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
-            else launch_p4<false, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per32, nsplit);
+            // split-K: partial slabs + reduce when the registered workspace is large enough, else f32 atomics
+            const bool slabs = ep.atomic && nsplit > 1 && ldc == N && (N % 4 == 0) && g_slab_ws &&
+                               (size_t)nsplit * M * N * 4 <= g_slab_bytes && !(flags & 128);
+            Epilogue ep2 = ep;
+            if (slabs) ep2.atomic = 0;
+            const bool swap = !ep2.atomic;
+            void* Cdst = slabs ? (void*)g_slab_ws : C;
+            const int64_t sstride = slabs ? (int64_t)M * N : 0;
+            if (!ta && !tb) launch_p4<true, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
+            else if (!ta && tb) launch_p4<true, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
+            else if (ta && !tb) launch_p4<false, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
+            else launch_p4<false, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
+            if (slabs) {
+                const int64_t n4 = (int64_t)M * N / 4;
+                gemm_slab_reduce_kernel<<<(int)std::min<int64_t>(cdiv64(n4, 256), 2048), 256, 0, s>>>(g_slab_ws, (float*)C, n4, n4, nsplit);
+            }
         } else if (big) {
             const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, H_BM);
             const int nsplit = cdiv(nk, per);

@@ -80,6 +80,8 @@ struct cmp_model {
     int32_t *row_correct = nullptr, *x_dev = nullptr, *y_dev = nullptr;
     void *dx = nullptr, *dr = nullptr, *tmpE = nullptr, *dmask = nullptr, *dfc = nullptr, *dqkv = nullptr;
     void* ln_ws = nullptr;
+    void* slab = nullptr;              // split-K slab workspace (deterministic mode only)
+    int64_t slab_bytes = 0;
     Metrics* metrics = nullptr;        // device
     Metrics* metrics_host = nullptr;   // pinned
     float* dp_metrics = nullptr;       // device [2] for the cross-rank mean

@@ -354,6 +354,14 @@ int ensure_workspace(cmp_model* m, int B, int T) {
     CHECK_RC(dev_alloc(m, &m->dmask, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->dfc, (size_t)M * 4 * E * es));
     CHECK_RC(dev_alloc(m, &m->dqkv, (size_t)M * 3 * E * es));
+    {   // COMPOSER_DETERMINISTIC=1: split-K wgrads write per-split slabs and reduce them in a fixed order instead of
+        // f32 atomics (bitwise reproducible steps; measured ~7 % slower at C2)
+        const char* det = getenv("COMPOSER_DETERMINISTIC");
+        if (det && det[0] == '1') {
+            m->slab_bytes = (int64_t)64 * E * E * 4 + (int64_t)64 * m->V * E * 4;
+            CHECK_RC(dev_alloc(m, &m->slab, (size_t)m->slab_bytes));
+        }
+    }
     CHECK_RC(dev_alloc(m, &m->ln_ws, (size_t)cmp_k_layernorm_bwd_ws((int)std::min<int64_t>(M, 1 << 30), E)));
     return CMP_OK;
 }
@@ -381,8 +389,12 @@ static int drop_apply(cmp_model* m, const void* in, void* out, int64_t n, float 
 static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                 int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
                 int splitk, float p_drop, uint32_t rng_stream, int flags = 0) {
-    return cmp_k_gemm(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
-                      out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags);
+    const bool use_slab = splitk > 1 && m->slab != nullptr;
+    if (use_slab) cmp_gemm_set_workspace(m->slab, m->slab_bytes);     // registered only around this launch
+    int rc = cmp_k_gemm(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
+                        out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags);
+    if (use_slab) cmp_gemm_set_workspace(nullptr, 0);
+    return rc;
 }
 
 int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step) {

@@ -160,6 +160,10 @@ int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
 #define CMP_GEMM_TILE256 8      /* tests/bench: force the persistent 256x256 2-stage kernel */
 #define CMP_GEMM_P4 16          /* tests/bench: force the persistent deep-pipeline (BK=32) kernel */
 #define CMP_GEMM_P4_128 32      /* with CMP_GEMM_P4: 128x256 tile / 4 waves / 3 stages / 2 workgroups per CU instead of 256x256 / 8 waves / 4 stages */
+/* Registers a device workspace for split-K reductions: with it, split-K launches write per-split fp32 partial tiles and
+ * fold them in a fixed order (reproducible, no float atomics); without it (or if too small: splitk*M*N*4 bytes) they
+ * accumulate with f32 atomics.  flags & 128 forces the atomic path. */
+int cmp_gemm_set_workspace(void* ws_dev, int64_t bytes);
 int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype);
 /* causal attention on qkv [B,T,3E] (head-merged, transformer.py:417): o [B,T,E], lse fp32 [B,H,T] */
 int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D,

@@ -153,10 +153,13 @@ def test_gemm_epilogues(lib, dtype, flags):
 
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
-@pytest.mark.parametrize("flags", [4, 8, 16, 48])
+@pytest.mark.parametrize("flags", [4, 8, 16, 48, 16 | 128])
 def test_gemm_wgrad_shape_large_k(lib, dtype, flags):
-    """wgrad: contraction over tokens (K=4096) with split-K atomics; ragged output (V=390 rows)."""
+    """wgrad: contraction over tokens (K=4096), split-K via partial slabs + ordered reduce (flags 16, 48: a workspace is
+    registered) or f32 atomics (other kernels, or flag 128); ragged output (V=390 rows)."""
     M, N, K = 390, 128, 4096
+    ws = torch.empty(8 * M * N + 64, device="cuda")
+    ck(lib, lib.cmp_gemm_set_workspace(P(ws), ws.numel() * 4))
     g = torch.Generator().manual_seed(11)
     At = dev(torch.randn(K, 448, generator=g) * 0.1, dtype)       # stored [K][ld=448], logical A[m,k]=At[k,m]
     At[:, 390:] = 0
@@ -165,6 +168,11 @@ def test_gemm_wgrad_shape_large_k(lib, dtype, flags):
     out = gemm(lib, dtype, 1, 0, At, B, M, N, K, out_fp32=True, splitk=8, C0=C0, flags=flags)
     ref = At.double()[:, :390].t() @ B.double()
     assert rel_err(out, ref) < TOL[dtype]
+    if dtype == BF16 and flags in (16, 48):          # the slab path is bitwise reproducible
+        C1 = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+        out2 = gemm(lib, dtype, 1, 0, At, B, M, N, K, out_fp32=True, splitk=8, C0=C1, flags=flags)
+        assert torch.equal(out, out2)
+    ck(lib, lib.cmp_gemm_set_workspace(None, 0))
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
