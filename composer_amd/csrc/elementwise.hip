@@ -126,13 +126,17 @@ template <typename T, int MAXI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const T* __restrict__ resid,
-                                     T* __restrict__ dx, float* __restrict__ ws, int rows, int E) {
+                                     T* __restrict__ dx, float* __restrict__ ws, int rows, int E,
+                                     T* __restrict__ dmask, int want_colsum, DropCfg drop) {
+    // optional fused consumer prologue: the output dx is the gradient of a residual branch's dropout output
+    // (x + dropout(proj(..))): dmask = dx * mask/(1-p) feeds that projection's wgrad/dgrad and its column sums are the
+    // projection's bias gradient (third partial, ws[wg][2] -> cs)
     constexpr int VN = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [waves][2][E]
+    extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [waves][3][E]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     const int chunks = E / VN;
-    float dg[MAXI][VN], db[MAXI][VN], gm[MAXI][VN];
+    float dg[MAXI][VN], db[MAXI][VN], gm[MAXI][VN], cs[MAXI][VN];
 #pragma unroll
     for (int i = 0; i < MAXI; i++) {
         int c = lane + 64 * i;
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int j = 0; j < VN; j++) {
             dg[i][j] = 0.f;
             db[i][j] = 0.f;
+            cs[i][j] = 0.f;
             gm[i][j] = (c < chunks) ? gamma[c * VN + j] : 0.f;
         }
     }
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
-                Vec16<T> o, r;
+                Vec16<T> o, r, om;
                 if (resid) r = ld16(resid + (int64_t)row * E + c * VN);
 #pragma unroll
                 for (int j = 0; j < VN; j++) {
@@ -180,13 +185,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     float v = rs * (g - s1 - xh * s2);
                     if (resid) v += r.get(j);
                     o.set(j, v);
+                    if (want_colsum) {
+                        // the consumer sees the STORED (rounded) value
+                        float vm = apply_drop(drop, (uint64_t)row * E + c * VN + j, o.get(j));
+                        om.set(j, vm);
+                        cs[i][j] += om.get(j);
+                    }
                 }
                 st16(dx + (int64_t)row * E + c * VN, o);
+                if (dmask) st16(dmask + (int64_t)row * E + c * VN, om);
             }
         }
     }
     // cross-wave reduction of the parameter-gradient partials
-    float* sm = ln_smem + (size_t)wave * 2 * E;
+    float* sm = ln_smem + (size_t)wave * 3 * E;
 #pragma unroll
     for (int i = 0; i < MAXI; i++) {
         int c = lane + 64 * i;
@@ -195,26 +207,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             for (int j = 0; j < VN; j++) {
                 sm[c * VN + j] = dg[i][j];
                 sm[E + c * VN + j] = db[i][j];
+                sm[2 * E + c * VN + j] = cs[i][j];
             }
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * E; e += blockDim.x) {
+    for (int e = threadIdx.x; e < 3 * E; e += blockDim.x) {
         float a = 0.f;
-        for (int w = 0; w < wpb; w++) a += ln_smem[(size_t)w * 2 * E + e];
-        ws[(size_t)blockIdx.x * 2 * E + e] = a;
+        for (int w = 0; w < wpb; w++) a += ln_smem[(size_t)w * 3 * E + e];
+        ws[(size_t)blockIdx.x * 3 * E + e] = a;
     }
 }
 
 // grid (ceil(2E/256), slices): each thread folds nparts/slices partials, then one atomic per slice
 __global__ void ln_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int nparts, int E) {
+                                       float* __restrict__ dbeta, float* __restrict__ colsum, int nparts, int E) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * E) return;
+    if (e >= (colsum ? 3 : 2) * E) return;
     float a = 0.f;
-    for (int p = blockIdx.y; p < nparts; p += gridDim.y) a += ws[(size_t)p * 2 * E + e];
+    for (int p = blockIdx.y; p < nparts; p += gridDim.y) a += ws[(size_t)p * 3 * E + e];
     if (e < E) atomicAdd(dgamma + e, a);
-    else atomicAdd(dbeta + (e - E), a);
+    else if (e < 2 * E) atomicAdd(dbeta + (e - E), a);
+    else atomicAdd(colsum + (e - 2 * E), a);
 }
 
 // =================================================================================================
@@ -467,25 +481,36 @@ extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gam
 
 static int ln_bwd_grid(int rows) { return std::max(1, std::min(cdiv(rows, 8), 2048)); }
 
-extern "C" int64_t cmp_k_layernorm_bwd_ws(int rows, int E) { return (int64_t)ln_bwd_grid(rows) * 2 * E * sizeof(float); }
+extern "C" int64_t cmp_k_layernorm_bwd_ws(int rows, int E) { return (int64_t)ln_bwd_grid(rows) * 3 * E * sizeof(float); }
 
 extern "C" int cmp_k_layernorm_bwd(void* stream, const void* dy, const void* x, const float* gamma, const float* mean,
                                    const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta,
                                    void* ws, int rows, int E, int dtype) {
+    return cmp_k_layernorm_bwd_fused(stream, dy, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, ws, rows, E, dtype,
+                                     nullptr, nullptr, 0.f, 0, 0);
+}
+
+extern "C" int cmp_k_layernorm_bwd_fused(void* stream, const void* dy, const void* x, const float* gamma, const float* mean,
+                                         const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta,
+                                         void* ws, int rows, int E, int dtype, void* dmask, float* colsum, float p_drop,
+                                         uint64_t seed, uint32_t rng_stream) {
     int rc = ln_check(E, dtype);
     if (rc) return rc;
     if (rows == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = ln_bwd_grid(rows);
-    size_t smem = (size_t)4 * 2 * E * sizeof(float);
+    size_t smem = (size_t)4 * 3 * E * sizeof(float);
     const int vn = dtype == CMP_BF16 ? 8 : 4;
     const int maxi = cdiv(E / vn, 64);
-#define LN_BWD(TT, MI) layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E)
+    DropCfg dcfg = make_drop(p_drop, seed, rng_stream);
+    if (p_drop <= 0.f) dmask = nullptr;          // no mask: the consumer reads dx itself
+    const int want_cs = colsum != nullptr;
+#define LN_BWD(TT, MI) layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E, (TT*)dmask, want_cs, dcfg)
     if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
     else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
 #undef LN_BWD
     KERNEL_CHECK();
-    ln_param_reduce_kernel<<<dim3(cdiv(2 * E, 256), std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, grid, E);
+    ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);
     KERNEL_CHECK();
     return CMP_OK;
 }

@@ -468,8 +468,12 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                   std::max(2, wgrad_splits(M, V, E)), 0.f, 0));
     CHECK_RC(gemm(m, 0, 0, M, E, V, m->dlogits, m->ldz, m->w(m->off_wte), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0,
                   1, 0.f, 0, CMP_GEMM_KPAD_ZERO));    // dlogits rows are zero-padded to ldz (softmax_xent kernel)
-    CHECK_RC(cmp_k_layernorm_bwd(s, m->tmpE, m->xs[m->L], m->P + m->off_lnf_g, m->lnf_mean, m->lnf_rstd, nullptr, m->dx,
-                                 m->G + m->off_lnf_g, m->G + m->off_lnf_b, m->ln_ws, M, E, dt));
+    // dx of every LayerNorm backward below is the gradient of the previous residual branch's dropout output, so the
+    // kernel also emits that branch's masked gradient (dmask) and bias gradient (column sums)
+    CHECK_RC(cmp_k_layernorm_bwd_fused(s, m->tmpE, m->xs[m->L], m->P + m->off_lnf_g, m->lnf_mean, m->lnf_rstd, nullptr, m->dx,
+                                       m->G + m->off_lnf_g, m->G + m->off_lnf_b, m->ln_ws, M, E, dt, m->dmask,
+                                       m->G + m->lo[m->L - 1].pr_b, pr, m->cfg.seed, drop_stream(step, m->L - 1, 3)));
+    bool dmo_ready = true;      // dmask / pr_b of the current layer already produced
     if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total));
     for (int i = m->L - 1; i >= 0; i--) {
         const LayerOff& o = m->lo[i];
@@ -477,12 +481,12 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         // ---- MLP: x_out = r + dropout(gelu(n.Wfc+b).Wpr+b)
         const void* dmo = m->dx;
         if (pr > 0.f) {
-            CHECK_RC(drop_apply(m, m->dx, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 3)));
+            if (!dmo_ready) CHECK_RC(drop_apply(m, m->dx, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 3)));
             dmo = m->dmask;
         }
         CHECK_RC(gemm(m, 1, 0, 4 * E, E, M, a.g, 4 * E, dmo, E, m->G + o.pr_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, 4 * E, E)), 0.f, 0));
-        CHECK_RC(cmp_k_colsum(s, dmo, E, m->G + o.pr_b, M, E, dt));
+        if (!dmo_ready) CHECK_RC(cmp_k_colsum(s, dmo, E, m->G + o.pr_b, M, E, dt));
         CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, dmo, E, m->w(o.pr_w), E, m->dfc, 4 * E, nullptr, 2, a.fc, 4 * E, nullptr, 0, 0, 1,
                       0.f, 0));                                                    // dfc = (dmo.Wpr^T) * gelu'(fc)
         CHECK_RC(gemm(m, 1, 0, E, 4 * E, M, a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
@@ -491,8 +495,9 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr,
                           0, 0, 1, 0.f, 0));                                       // dn
-            CHECK_RC(cmp_k_layernorm_bwd(s, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr,
-                                         m->G + o.ln2_g, m->G + o.ln2_b, m->ln_ws, M, E, dt));   // dr = dx + LN2'(dn)
+            CHECK_RC(cmp_k_layernorm_bwd_fused(s, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr,
+                                               m->G + o.ln2_g, m->G + o.ln2_b, m->ln_ws, M, E, dt, m->dmask, m->G + o.proj_b, pr,
+                                               m->cfg.seed, drop_stream(step, i, 2)));   // dr = dx + LN2'(dn); dao, b_proj grad
         } else {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->dr, E, nullptr, 0, nullptr, 0, m->dx, E,
                           0, 1, 0.f, 0));                                          // dr = dx + dn
@@ -500,12 +505,12 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         // ---- attention: r = u + dropout(att.Wproj+b)
         const void* dao = m->dr;
         if (pr > 0.f) {
-            CHECK_RC(drop_apply(m, m->dr, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 2)));
+            if (!ln) CHECK_RC(drop_apply(m, m->dr, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 2)));
             dao = m->dmask;
         }
         CHECK_RC(gemm(m, 1, 0, E, E, M, a.att, E, dao, E, m->G + o.proj_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, E, E)), 0.f, 0));
-        CHECK_RC(cmp_k_colsum(s, dao, E, m->G + o.proj_b, M, E, dt));
+        if (!ln) CHECK_RC(cmp_k_colsum(s, dao, E, m->G + o.proj_b, M, E, dt));
         CHECK_RC(gemm(m, 0, 1, M, E, E, dao, E, m->w(o.proj_w), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
                       0));                                                         // datt
         CHECK_RC(cmp_k_attn_bwd(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
@@ -516,9 +521,14 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
                           E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T
-            CHECK_RC(cmp_k_layernorm_bwd(s, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx,
-                                         m->G + o.ln1_g, m->G + o.ln1_b, m->ln_ws, M, E, dt));   // dx_in = LN1'(du): no skip
+            // dx_in = LN1'(du): no skip connection around LN1; feeds layer i-1's MLP branch (or the embedding for i = 0)
+            CHECK_RC(cmp_k_layernorm_bwd_fused(s, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx,
+                                               m->G + o.ln1_g, m->G + o.ln1_b, m->ln_ws, M, E, dt, i > 0 ? m->dmask : nullptr,
+                                               i > 0 ? m->G + m->lo[i - 1].pr_b : nullptr, pr, m->cfg.seed,
+                                               drop_stream(step, i > 0 ? i - 1 : 0, 3)));
+            dmo_ready = true;
         } else {
+            dmo_ready = false;
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->dx, E, nullptr, 0, nullptr, 0, m->dr, E,
                           0, 1, 0.f, 0));
         }

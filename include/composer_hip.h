@@ -142,6 +142,12 @@ int cmp_k_layernorm_bwd(void* stream, const void* dy, const void* x, const float
                         const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta,
                         void* ws, int rows, int E, int dtype);
 int64_t cmp_k_layernorm_bwd_ws(int rows, int E);
+/* same, plus the prologue of the projection that consumes dx as the gradient of `x + dropout(proj)`: colsum[E] +=
+ * column sums of dropout_grad(dx) (that projection's bias gradient) and, when p_drop > 0, dmask = dx * mask/(1-p). */
+int cmp_k_layernorm_bwd_fused(void* stream, const void* dy, const void* x, const float* gamma, const float* mean,
+                              const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta,
+                              void* ws, int rows, int E, int dtype, void* dmask, float* colsum, float p_drop,
+                              uint64_t seed, uint32_t rng_stream);
 /* C[M,N] = epilogue(A.B): ta=0: A is [M,K] (lda); ta=1: A stored [K,M].  tb=0: B stored [K,N]; tb=1: B stored [N,K].
  * epilogue: +bias[N] (fp32, may be NULL); act: 0 none, 1 gelu (pre-activation stored to aux if aux!=NULL),
  * 2 multiply by gelu'(aux[m,n]); dropout (p>0) then +resid[m,n] (may be NULL).  out_fp32: C is fp32 regardless of

@@ -201,6 +201,17 @@ def test_layernorm_fwd_bwd(lib, dtype, rows, E):
     assert rel_err(dx, torch.tensor(dxr) + resid.double().cpu()) < TOL[dtype]
     assert rel_err(dg, torch.tensor(dgr) + 1.0) < 3e-5 * math.sqrt(rows) + (0 if dtype == FP32 else 1e-3)
     assert rel_err(db, torch.tensor(dbr) - 1.0) < 3e-5 * math.sqrt(rows) + (0 if dtype == FP32 else 1e-3)
+    # fused consumer prologue: dropout-gradient mask of dx and its column sums
+    dx2 = torch.empty_like(x); dmask = torch.zeros_like(x)
+    dg2 = torch.zeros(E, device="cuda"); db2 = torch.zeros(E, device="cuda"); cs = torch.full((E,), 2.0, device="cuda")
+    ck(lib, lib.cmp_k_layernorm_bwd_fused(stream(), P(dy), P(x), P(gamma), P(mean), P(rstd), P(resid), P(dx2), P(dg2), P(db2), P(ws),
+                                          rows, E, dtype, P(dmask), P(cs), 0.25, 41, 6))
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    keep = torch.tensor(O.dropout_keep(41, 6, np.arange(rows * E, dtype=np.uint64), 0.25).reshape(rows, E) / 0.75)
+    want = dx.double().cpu() * keep
+    assert rel_err(dmask, want) < TOL[dtype]
+    assert rel_err(cs, dmask.double().cpu().sum(0) + 2.0) < 3e-5 * math.sqrt(rows) + (0 if dtype == FP32 else 2e-3)
 
 
 # ------------------------------------------------------------------------------------------ attention
