@@ -5,7 +5,7 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
 
-Workload (BASELINE config 2/3): 6L/8H/d512 decoder, window 1024, B=32 sequences per GPU (weak scaling),
+Workload (BASELINE config 2/3): 6L/8H/d512 decoder, window 1024, B=128 sequences per GPU (weak scaling; --batch to change),
 bf16 activations with fp32 master weights/accumulation, dropout 0.1 (default_config.yml:39-40), lr 1e-3.
 Inputs are generated up front and live in HBM before the timed region.
 
@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 V, E, H, L, W, T = 390, 512, 8, 6, 1024, 1024
-B_PER_GPU = 32
+B_PER_GPU = 128       # per-GPU batch: not fixed by BASELINE; sweep in DESIGN.md section 7 (B=32: 3.28 M tok/s, 128: 3.84 M)
 LR = 1e-3
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0

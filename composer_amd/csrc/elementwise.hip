@@ -225,7 +225,16 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ ws, float* __re
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (colsum ? 3 : 2) * E) return;
     float a = 0.f;
-    for (int p = blockIdx.y; p < nparts; p += gridDim.y) a += ws[(size_t)p * 3 * E + e];
+    const int stride = gridDim.y;
+    int p = blockIdx.y;
+    for (; p + 7 * stride < nparts; p += 8 * stride) {       // 8 independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = ws[(size_t)(p + u * stride) * 3 * E + e];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a += v[u];
+    }
+    for (; p < nparts; p += stride) a += ws[(size_t)p * 3 * E + e];
     if (e < E) atomicAdd(dgamma + e, a);
     else if (e < 2 * E) atomicAdd(dbeta + (e - E), a);
     else atomicAdd(colsum + (e - 2 * E), a);
