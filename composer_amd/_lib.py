@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcomposer_hip.so")
+# COMPOSER_HIP_LIB: kernel A/B runs load another build of the same library (tools/ab_build.py); never a CPU path
+LIB_PATH = os.environ.get("COMPOSER_HIP_LIB") or os.path.join(_HERE, "lib", "libcomposer_hip.so")
 
 CMP_FP32, CMP_BF16 = 0, 1
 DECODE_LITERAL, DECODE_KV = 0, 1
@@ -70,6 +71,7 @@ SIGNATURES = {
     "cmp_k_layernorm_bwd_fused": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _P, _f, _u64, _u32]),
     "cmp_k_gemm": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _i, _i, _f, _u64, _u32, _i]),
     "cmp_gemm_set_workspace": (_i, [_P, _i64]),
+    "cmp_gemm_set_stamps": (_i, [_P]),
     "cmp_k_colsum": (_i, [_P, _P, _i, _P, _i, _i, _i]),
     "cmp_k_attn_fwd": (_i, [_P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_attn_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _f, _u64, _u32]),

@@ -14,6 +14,7 @@
 //                           fragments by two ds_read_b64_tr_b16 (hardware transpose, conflict-free).
 // fp32 path (parity mode): v_mfma_f32_16x16x4_f32 = exact fp32 fma chains, 64x64x16 tile.
 #include "common.h"
+#include <vector>
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -400,6 +401,189 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& ep, void* C, int
     }
 }
 
+
+// ---- split epilogue for the persistent kernels: the memory operands of a chunk (gelu' input, residual) are fetched
+// one accumulator row-group AHEAD of their use and the bias once per item -- C may alias them as far as the compiler
+// knows, so inside epilogue_store8 every chunk re-loads them after the previous chunk's store (a serial L2 round trip
+// per chunk: 16 per wave and item, measured ~25k cycles of a 74k-cycle c_attn item).
+struct EpiIn {
+    bf16x8 v;          // gelu' input (act == 2) or the residual; no epilogue in the model uses both
+};
+__device__ __forceinline__ void epi_bias8(const Epilogue& ep, int col, int N, float (&b)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) b[j] = 0.f;
+    if (!ep.bias || col >= N) return;
+    if (col + 8 <= N) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col), b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { b[j] = b0[j]; b[4 + j] = b1[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (col + j < N) b[j] = ep.bias[col + j];
+    }
+}
+__device__ __forceinline__ EpiIn epi_fetch8(const Epilogue& ep, int row, int col, bool ok) {
+    EpiIn in;
+#pragma unroll
+    for (int j = 0; j < 8; j++) in.v[j] = (bf16_t)0.f;
+    if (ok) {
+        if (ep.act == 2) in.v = *reinterpret_cast<const bf16x8*>((const bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col);
+        else if (ep.resid) in.v = *reinterpret_cast<const bf16x8*>((const bf16_t*)ep.resid + (int64_t)row * ep.ldr + col);
+    }
+    return in;
+}
+__device__ __forceinline__ void epi_finish8(const Epilogue& ep, void* C, int ldc, int row, int col, int N, f32x4 v0, f32x4 v1,
+                                            const float (&b)[8], const EpiIn& in) {
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] += b[j];
+    if (ep.act == 1) {
+        if (ep.aux) {
+            bf16x8 a;
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x8*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col) = a;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = gelu_f<false>(v[j]);
+    } else if (ep.act == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)in.v[j]);
+    }
+    if (ep.drop.thr) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+    }
+    if (ep.resid) {
+        if (ep.act == 2) {      // not used by the model: fall back to an in-place load
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>((const bf16_t*)ep.resid + (int64_t)row * ep.ldr + col);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += (float)r[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += (float)in.v[j];
+        }
+    }
+    if (ep.dbg_nostore && v[0] != 12345.678f) return;
+    if (ep.out_fp32) {
+        float* o = (float*)C + (int64_t)row * ldc + col;
+        if (col + 8 <= N) {
+            *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (col + j < N) o[j] = v[j];
+        }
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8*>((bf16_t*)C + (int64_t)row * ldc + col) = o;     // ldc is padded to a multiple of 8
+    }
+}
+
+
+// ---- compile-time epilogue kinds for the persistent kernels (full 256x256 tiles, bf16 output) -------------------------
+// The generic epilogue branches at run time on the Epilogue fields; with global loads under those branches the
+// compiler's waitcnt insertion falls back to `s_waitcnt vmcnt(0)` in every chunk, i.e. every chunk waits for the
+// previous chunk's STORES to be acknowledged (measured with in-kernel stamps: 18-50k cycles for the 16 chunks of a
+// tile, the store round trip serialised 16 times).  A kind fixes what touches memory inside the loop, the loop is
+// straight-line code, the operand loads run two chunks ahead of their use and the waits are counted: stores are
+// fire-and-forget.
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_AUX = 2, EPI_RESID = 3, EPI_GELUGRAD = 4 };
+//   EPI_PLAIN    : C = acc (+ bias)                                  c_attn forward; dgrad without epilogue operands
+//   EPI_GELU_AUX : aux = acc + bias ; C = gelu(aux)                  c_fc forward
+//   EPI_RESID    : C = drop(acc (+ bias)) + resid                    both c_proj forward; dgrad c_attn (+ residual grad)
+//   EPI_GELUGRAD : C = acc * gelu'(aux)                              dgrad through the MLP activation
+template <int KIND, bool XOR_STG>
+__device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict__ C, int ldc, int row0, int col, float* stg,
+                                         int lane, const f32x4 (&acc)[8][4]) {
+    constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
+    constexpr int AHEAD = 2;
+    float b[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) b[j] = 0.f;
+    if (KIND != EPI_GELUGRAD && ep.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col), b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { b[j] = b0[j]; b[4 + j] = b1[j]; }
+    }
+    const int rl = lane >> 3;
+    const bf16_t* __restrict__ src = KIND == EPI_RESID ? (const bf16_t*)ep.resid : (const bf16_t*)ep.aux;
+    const int lds = KIND == EPI_RESID ? ep.ldr : ep.ldaux;
+    bf16x8 opnd[16];
+    auto fetch = [&](int c) {
+        const int row = row0 + (c >> 1) * 16 + (c & 1) * 8 + rl;
+        opnd[c] = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col);
+    };
+    if (LOADS) {
+#pragma unroll
+        for (int c = 0; c < AHEAD; c++) fetch(c);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int i = c >> 1, it = c & 1;
+        if (it == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (XOR_STG) {
+                    const int r = lane & 15, cc = j * 4 + (lane >> 4);
+                    *reinterpret_cast<f32x4*>(stg + r * 64 + ((cc ^ r) << 2)) = acc[i][j];
+                } else {
+                    *reinterpret_cast<f32x4*>(stg + (lane & 15) * 68 + j * 16 + (lane >> 4) * 4) = acc[i][j];
+                }
+            }
+        }
+        if (LOADS && c + AHEAD < 16) fetch(c + AHEAD);
+        const int r16 = it * 8 + rl;
+        f32x4 v0, v1;
+        if (XOR_STG) {
+            const int c0 = (lane & 7) * 2;
+            v0 = *reinterpret_cast<const f32x4*>(stg + r16 * 64 + ((c0 ^ r16) << 2));
+            v1 = *reinterpret_cast<const f32x4*>(stg + r16 * 64 + (((c0 + 1) ^ r16) << 2));
+        } else {
+            v0 = *reinterpret_cast<const f32x4*>(stg + r16 * 68 + (lane & 7) * 8);
+            v1 = *reinterpret_cast<const f32x4*>(stg + r16 * 68 + (lane & 7) * 8 + 4);
+        }
+        const int row = row0 + i * 16 + r16;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (KIND != EPI_GELUGRAD) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += b[j];
+        }
+        if (KIND == EPI_GELU_AUX) {
+            bf16x8 a;
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x8*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col) = a;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = gelu_f<false>(v[j]);
+        } else if (KIND == EPI_GELUGRAD) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)opnd[c][j]);
+        } else if (KIND == EPI_RESID) {
+            if (ep.drop.thr) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += (float)opnd[c][j];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
+    }
+}
+// the kind a launch may use (full tiles only; everything else takes the generic run-time epilogue)
+static int epi_kind_of(const Epilogue& ep, int M, int N, bool swap, bool slabs) {
+    if (!swap || slabs || ep.out_fp32 || ep.dbg_nostore || ep.atomic || M % 256 || N % 256) return EPI_GENERIC;
+    if (ep.act == 1) return (ep.aux && !ep.resid && !ep.drop.thr) ? EPI_GELU_AUX : EPI_GENERIC;
+    if (ep.act == 2) return (!ep.resid && !ep.drop.thr && !ep.bias) ? EPI_GELUGRAD : EPI_GENERIC;
+    if (ep.resid) return EPI_RESID;
+    return ep.drop.thr ? EPI_GENERIC : EPI_PLAIN;
+}
+
 template <bool A_KM, bool B_KM, bool SWAP>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
@@ -558,7 +742,7 @@ __device__ __forceinline__ bf16x8 h_frag(const char* img, int t16, int ks, int l
     }
 }
 
-template <bool A_KM, bool B_KM, bool SWAP>
+template <bool A_KM, bool B_KM, bool SWAP, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
                                                                Epilogue ep, int ktiles_per_split, int nsplit, int tiles_n,
@@ -648,20 +832,33 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         }
         if (SWAP) {
             float* stg = reinterpret_cast<float*>(smem + 2 * H_IMG) + wave * (16 * 68);   // stage 1: [16][68] floats per wave
+            const int col = cn0 + wn * 64 + (lane & 7) * 8;
+            if constexpr (EPI != EPI_GENERIC) {
+                epi_tile<EPI, false>(ep, (bf16_t*)C, ldc, cm0 + wm * 128, col, stg, lane, acc);
+            } else {
+            const int rbase = cm0 + wm * 128 + (lane >> 3);
+            float bias8[8];
+            epi_bias8(ep, col, N, bias8);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
+                EpiIn in[2];          // fetched before the staging round trip through LDS, used after it
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int row = rbase + i * 16 + it * 8;
+                    in[it] = epi_fetch8(ep, row, col, row < M && col < N);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     *reinterpret_cast<f32x4*>(stg + (lane & 15) * 68 + j * 16 + (lane >> 4) * 4) = acc[i][j];
 #pragma unroll
                 for (int it = 0; it < 2; it++) {
                     const int rl = it * 8 + (lane >> 3);
-                    const int row = cm0 + wm * 128 + i * 16 + rl;
-                    const int col = cn0 + wn * 64 + (lane & 7) * 8;
+                    const int row = rbase + i * 16 + it * 8;
                     f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rl * 68 + (lane & 7) * 8);
                     f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rl * 68 + (lane & 7) * 8 + 4);
-                    if (row < M && col < N) epilogue_store8(ep, C, ldc, row, col, N, v0, v1);
+                    if (row < M && col < N) epi_finish8(ep, C, ldc, row, col, N, v0, v1, bias8, in[it]);
                 }
+            }
             }
         } else {
             // split-K items: plain f32 atomics, 16 consecutive floats per row per wave-instruction
@@ -770,11 +967,14 @@ __device__ __forceinline__ bf16x8 p_frag(const char* img, int t16, int lane) {
 }
 
 // NWM: wave rows (1: 128x256 tile, 4 waves, 2 workgroups per CU; 2: 256x256 tile, 8 waves, 1 per CU).  NST: LDS stages.
-template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST>
+template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST, bool DIAG = false, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                     const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
                                                                     Epilogue ep, int ksteps_per_split, int nsplit, int tiles_n,
-                                                                    int ntiles, int64_t slab_stride) {
+                                                                    int ntiles, int64_t slab_stride,
+                                                                    unsigned long long* stamps) {
+    // DIAG instantiation only (tools/gemm_timeline.py): workgroup 17, wave 0 records s_memtime at fixed points of its
+    // first items into a buffer nothing else reads.  The product instantiation compiles the stamps away.
     constexpr int BM = 128 * NWM;
     constexpr int A_IMG = BM * P_BK * 2, B_IMG = 256 * P_BK * 2, STAGE = A_IMG + B_IMG;
     constexpr int A_ROWB = BM * 2;                    // row bytes of a contraction-slow A image
@@ -809,8 +1009,17 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
 
     int item = blockIdx.x;
     if (item >= nitems) return;
+    int nstamp = 0;
+    auto stamp = [&](int id) {
+        if (DIAG && stamps && blockIdx.x == 17 && tid == 0 && nstamp < 250) {
+            stamps[2 * nstamp] = (unsigned long long)id;
+            stamps[2 * nstamp + 1] = __builtin_amdgcn_s_memtime();
+            nstamp++;
+        }
+    };
     int m0, n0, kt0, kt1;
     item_coords(item, m0, n0, kt0, kt1);
+    stamp(1);
     v4i32 ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
     v4i32 rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
     auto issue = [&](int kt, int buf) {
@@ -850,8 +1059,11 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
         if (n > 0) {
+            stamp(2);
             wait_younger(min(n, AHEAD) - 1);
+            stamp(3);
             __builtin_amdgcn_s_barrier();
+            stamp(4);
 #pragma unroll
             for (int j = 0; j < 4; j++) fb[j] = p_frag<B_KM, 512>(smem + A_IMG, wn * 4 + j, lane);
             fa0 = p_frag<A_KM, A_ROWB>(smem, wm * 8, lane);
@@ -868,9 +1080,13 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             auto sync_point = [&]() {
                 // stage t+1 must have landed; stages t+2 .. t+AHEAD-1 may still fly.  Past this barrier every wave has
                 // finished stage t-1, so its buffer takes stage t+AHEAD.
+                stamp(10);
                 wait_younger(min(n - t - 2, AHEAD - 2));
+                stamp(11);
                 __builtin_amdgcn_s_barrier();
+                stamp(12);
                 if (t + AHEAD < n) issue(kt0 + t + AHEAD, (t + AHEAD) % NST);
+                stamp(13);
                 if (t + 1 < n) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) fbn[j] = p_frag<B_KM, 512>(nia + A_IMG, wn * 4 + j, lane);
@@ -899,8 +1115,10 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         } else {
             for (int t = 0; t < n; t++) run_stage(t, std::integral_constant<int, -1>());
         }
+        stamp(20);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave has finished reading the stages of this item
+        stamp(21);
         const int cm0 = m0, cn0 = n0;
         // split-K with a slab workspace: every split writes its own fp32 partial tile with the ordinary full-line
         // epilogue (plain stores run ~4-5x the f32-atomic rate and the sum is reproducible); gemm_slab_reduce folds them
@@ -915,13 +1133,28 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             for (int i = 0; i < AHEAD; i++)
                 if (kt0 + i < kt1) issue(kt0 + i, i);              // the epilogue owns the B image of the last stage
         }
+        stamp(22);
         if (SWAP) {
             // per wave [16 rows][64 floats] = 4 KiB, 16-byte chunks xor-swizzled by the row
             float* stg = reinterpret_cast<float*>(smem + (NST - 1) * STAGE + A_IMG) + wave * (16 * 64);
             static_assert(NWAVES * 4096 <= B_IMG + (NWM == 2 ? A_IMG : 0), "epilogue staging must fit the last stage");
             if (NWM == 2) stg = reinterpret_cast<float*>(smem + (NST - 1) * STAGE) + wave * (16 * 64);
+            const int col = cn0 + wn * 64 + (lane & 7) * 8;
+            if constexpr (EPI != EPI_GENERIC) {
+                epi_tile<EPI, true>(ep, (bf16_t*)Cit, ldc, cm0 + wm * 128, col, stg, lane, acc);
+            } else {
+            const int rbase = cm0 + wm * 128 + (lane >> 3);
+            float bias8[8];
+            epi_bias8(ep, col, N, bias8);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
+                stamp(40 + i);
+                EpiIn in[2];          // fetched before the staging round trip through LDS, used after it
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int row = rbase + i * 16 + it * 8;
+                    in[it] = epi_fetch8(ep, row, col, row < M && col < N);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int r = lane & 15, c = j * 4 + (lane >> 4);
@@ -930,13 +1163,13 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
 #pragma unroll
                 for (int it = 0; it < 2; it++) {
                     const int rl = it * 8 + (lane >> 3);
-                    const int row = cm0 + wm * 128 + i * 16 + rl;
-                    const int col = cn0 + wn * 64 + (lane & 7) * 8;
+                    const int row = rbase + i * 16 + it * 8;
                     const int c0 = (lane & 7) * 2;
                     f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rl * 64 + ((c0 ^ rl) << 2));
                     f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rl * 64 + (((c0 + 1) ^ rl) << 2));
-                    if (row < M && col < N) epilogue_store8(ep, Cit, ldc, row, col, N, v0, v1);
+                    if (row < M && col < N) epi_finish8(ep, Cit, ldc, row, col, N, v0, v1, bias8, in[it]);
                 }
+            }
             }
         } else {
             float* Cf = (float*)C;
@@ -954,14 +1187,30 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                     }
                 }
         }
+        stamp(30);
         if (!has_next) break;
         item = next;
         // the epilogue's stores/atomics sit in the same vmcnt queue behind the prefetched stages: drain them so the
         // counted waits of the next item see only its own DMA (the other workgroup on the CU keeps the pipes busy)
+        // (leaving the stores in flight and allowing for them in the first counted waits measured 2-5 % SLOWER in a
+        // same-box A/B: the epilogue is ~4.5k of a ~55k-cycle item and the drain ~1k)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(31);
     }
 }
 
+// dynamic-LDS opt-in, once per kernel
+static void allow_smem(const void* kern, size_t smem) {
+    static std::vector<const void*> done;
+    if (std::find(done.begin(), done.end(), kern) != done.end()) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    done.push_back(kern);
+}
+static unsigned long long* g_gemm_stamps = nullptr;    // diagnostic only (cmp_gemm_set_stamps)
+extern "C" int cmp_gemm_set_stamps(void* dev_buf) {
+    g_gemm_stamps = (unsigned long long*)dev_buf;
+    return CMP_OK;
+}
 template <bool A_KM, bool B_KM, int NWM, int NST>
 static void launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
                           void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride) {
@@ -975,10 +1224,26 @@ static void launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
     }
     const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, BM);
     const int grid = std::min(ntiles * nsplit, NWM == 1 ? 512 : 256);
+    if constexpr (A_KM && !B_KM && NWM == 2 && NST == 4) {
+        // the forward layout carries the compile-time epilogue kinds (and the diagnostic timeline build)
+        const int kind = epi_kind_of(ep, M, N, swap, slab_stride != 0);
+        auto go = [&](auto kern) {
+            allow_smem((const void*)kern, smem);
+            kern<<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, slab_stride, g_gemm_stamps);
+        };
+        if (g_gemm_stamps && swap) {
+            if (kind == EPI_PLAIN) go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_PLAIN>);
+            else go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_GENERIC>);
+            return;
+        }
+        if (kind == EPI_PLAIN) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_PLAIN>); return; }
+        if (kind == EPI_GELU_AUX) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_GELU_AUX>); return; }
+        if (kind == EPI_RESID) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_RESID>); return; }
+    }
     if (swap)
-        gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, slab_stride);
+        gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, slab_stride, g_gemm_stamps);
     else
-        gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, (int64_t)0);
+        gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, (int64_t)0, g_gemm_stamps);
 }
 template <bool A_KM, bool B_KM>
 static void launch_p4(hipStream_t s, int cfg, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
@@ -1013,6 +1278,16 @@ static void launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, 
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
+    }
+    if constexpr (A_KM && B_KM) {        // the dgrad layout carries the compile-time epilogue kinds
+        const int kind = epi_kind_of(ep, M, N, swap, false);
+        auto go = [&](auto kern) {
+            allow_smem((const void*)kern, smem);
+            kern<<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
+        };
+        if (kind == EPI_PLAIN) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_PLAIN>); return; }
+        if (kind == EPI_RESID) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_RESID>); return; }
+        if (kind == EPI_GELUGRAD) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_GELUGRAD>); return; }
     }
     if (swap)
         gemm_bf16_256_kernel<A_KM, B_KM, true><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);

@@ -170,6 +170,9 @@ int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
  * fold them in a fixed order (reproducible, no float atomics); without it (or if too small: splitk*M*N*4 bytes) they
  * accumulate with f32 atomics.  flags & 128 forces the atomic path. */
 int cmp_gemm_set_workspace(void* ws_dev, int64_t bytes);
+/* diagnostic only: a device buffer of 500 uint64 receives (id, s_memtime) pairs from one workgroup of the next
+ * deep-pipeline GEMM launches (tools/gemm_timeline.py); pass NULL to switch it off. */
+int cmp_gemm_set_stamps(void* dev_buf);
 int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype);
 /* causal attention on qkv [B,T,3E] (head-merged, transformer.py:417): o [B,T,E], lse fp32 [B,H,T] */
 int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D,

@@ -152,6 +152,54 @@ def test_gemm_epilogues(lib, dtype, flags):
     assert rel_err(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (768, 1024, 96), (1024, 512, 512)])
+def test_gemm_epilogue_kinds_full_tiles(lib, tb, M, N, K):
+    """Full 256x256 tiles with bf16 output take the compile-time epilogue kinds (gemm.hip EPI_*: operand loads two
+    chunks ahead, counted waits) on the forward (tb=0, deep pipeline) and dgrad (tb=1, 2-stage 256) kernels.  Each kind
+    must agree with the fp64 reference and, element by element, with the run-time epilogue of the 128x128 kernel (flags=4)."""
+    g = torch.Generator().manual_seed(M + N + K + tb)
+    a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) * 0.2
+    A, B = dev(a, BF16), dev(b.t().contiguous() if tb else b, BF16)
+    bias = dev(torch.randn(N, generator=g))
+    resid = dev(torch.randn(M, N, generator=g), BF16)
+    pre = dev(torch.randn(M, N, generator=g), BF16)
+    acc = A.double() @ (B.double().t() if tb else B.double())
+    accb = acc + bias.double()
+
+    def both(**kw):
+        outs = []
+        for flags in (0, 4):
+            k2 = dict(kw)
+            if "aux_out" in k2:
+                k2.pop("aux_out")
+                k2["aux"] = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            out = gemm(lib, BF16, 0, tb, A, B, M, N, K, flags=flags, **k2)
+            outs.append((out, k2.get("aux") if "aux_out" in kw else None))
+        # element by element within one bf16 ulp of the other kernel (fma contraction may differ between kernels)
+        assert torch.allclose(outs[0][0].float(), outs[1][0].float(), rtol=2.0 ** -7, atol=2e-3)
+        if outs[0][1] is not None:
+            assert torch.allclose(outs[0][1].float(), outs[1][1].float(), rtol=2.0 ** -7, atol=2e-3)
+        return outs[0]
+
+    out, _ = both(bias=bias)                                             # EPI_PLAIN with bias
+    assert rel_err(out, accb) < TOL[BF16]
+    out, _ = both()                                                      # EPI_PLAIN without
+    assert rel_err(out, acc) < TOL[BF16]
+    out, aux = both(bias=bias, act=1, aux_out=True)                      # EPI_GELU_AUX
+    assert rel_err(aux, accb) < TOL[BF16]
+    assert rel_err(out, torch.tensor(O.gelu(accb.cpu().numpy()))) < TOL[BF16]
+    out, _ = both(bias=bias, resid=resid)                                # EPI_RESID
+    assert rel_err(out, accb + resid.double()) < TOL[BF16]
+    out, _ = both(resid=resid)                                           # EPI_RESID, no bias (dgrad c_attn)
+    assert rel_err(out, acc + resid.double()) < TOL[BF16]
+    out, _ = both(bias=bias, resid=resid, p_drop=0.25, seed=77, rng=9)   # EPI_RESID + dropout (oracle's mask)
+    keep = O.dropout_keep(77, 9, np.arange(M * N, dtype=np.uint64), 0.25).reshape(M, N)
+    assert rel_err(out, accb.cpu() * torch.tensor(keep / 0.75) + resid.double().cpu()) < TOL[BF16]
+    out, _ = both(act=2, aux=pre)                                        # EPI_GELUGRAD
+    assert rel_err(out, acc.cpu() * torch.tensor(O.gelu_grad(pre.double().cpu().numpy()))) < TOL[BF16]
+
+
 @pytest.mark.parametrize("dtype", [FP32, BF16])
 @pytest.mark.parametrize("flags", [4, 8, 16, 48, 16 | 128])
 def test_gemm_wgrad_shape_large_k(lib, dtype, flags):

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Builds a VARIANT of libcomposer_hip.so for same-box A/B timing: one source recompiled with extra -D flags, linked with
+the cached objects of the others into composer_amd/lib/<name>.so.  Run the arms in ONE gpurun call (boxes differ by
+up to ~10 %):   COMPOSER_HIP_LIB=composer_amd/lib/<name>.so python tools/kbench.py gemm
+    python tools/ab_build.py <name> <source.hip> -DFOO [-DBAR ...]
+"""
+import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from composer_amd import build as B
+
+def main():
+    name, src, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+    B.build(verbose=False)
+    obj = os.path.join(B.OBJ, "ab_%s_%s" % (name, src.replace(".hip", ".o")))
+    subprocess.run([B._hipcc()] + B.FLAGS + extra + ["-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
+    objs = [obj if s == src else os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B.SOURCES]
+    out = os.path.join(B.LIBDIR, name + ".so")
+    subprocess.run([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs +
+                   ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    print("built", out)
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,8 @@ from composer_amd import _lib
 lib = _lib.load()
 BF16 = 1
 GFLAGS = 0
-M, E, H, D, T, B = 32768, 512, 8, 64, 1024, 32
+B = int(os.environ.get('KB_B', '32'))
+M, E, H, D, T = B * 1024, 512, 8, 64, 1024
 
 
 def P(t):
@@ -72,7 +73,7 @@ def bench_gemm():
     tot += gemm_case("dgrad c_attn (+resid)", 0, 1, M, E, 3 * E, resid=True)
     for nm, m, n in (("wgrad mlp c_proj", 4 * E, E), ("wgrad c_fc", E, 4 * E), ("wgrad attn c_proj", E, E), ("wgrad c_attn", E, 3 * E)):
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
-        s = max(2, min(max(1, 768 // tiles), M // 256))
+        s = max(2, min(max(1, 768 // tiles), 32768 // 256))
         tot += gemm_case(nm, 1, 0, m, n, M, splitk=s, out_fp32=True)
     print("sum of the 12 per-layer GEMMs: %.1f us  (%.1f TFLOP/s average)" % (tot, 3 * 2.0 * M * 12 * E * E / tot / 1e6))
 
