@@ -112,9 +112,18 @@ static inline DropCfg make_drop(float p, uint64_t seed, uint32_t stream) {
     d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return d;
 }
-__device__ __forceinline__ float apply_drop(const DropCfg& d, uint64_t idx, float v) {
+// Flat sites (0 embedding sum, 2 attention c_proj output, 3 MLP output) are [token row, feature column] matrices and
+// use the same two-level mask as the attention probabilities: one full hash per row (amortised over the 8 columns a
+// lane handles), one 24-bit multiply + compare per element.  (The first version hashed the flat index with two
+// mix32 rounds per ELEMENT: 5 quarter-rate 32-bit multiplies, ~110 cycles per wave-element -- more epilogue time per
+// c_proj tile than its K=512 main loop.)   oracle: transformer_oracle.py::dropout_keep_rows
+__device__ __forceinline__ uint32_t drop_row_hash(const DropCfg& d, uint32_t row) { return attn_row_hash(d.seed, d.stream, row); }
+__device__ __forceinline__ float apply_drop_rc(const DropCfg& d, uint32_t rowhash, uint32_t col, float v) {
+    return attn_elem_hash(rowhash, col) >= d.thr ? v * d.scale : 0.0f;
+}
+__device__ __forceinline__ float apply_drop(const DropCfg& d, uint32_t row, uint32_t col, float v) {
     if (d.thr == 0u) return v;
-    return drop_hash(d.seed, d.stream, idx) >= d.thr ? v * d.scale : 0.0f;
+    return apply_drop_rc(d, drop_row_hash(d, row), col, v);
 }
 
 // ---- numeric helpers ----------------------------------------------------------------------------
@@ -134,13 +143,31 @@ template <bool EXACT> __device__ __forceinline__ float tanh_f(float x) {
     float e = __expf(2.0f * x);
     return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
 }
+// gelu(x) = 0.5 x (1 + tanh(u)), u = C (x + K x^3).  With 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)) =: s(x) the fast (bf16
+// kernels) form needs one v_exp_f32 and one v_rcp_f32 and no IEEE division sequence (__frcp_rn expands to ~10
+// instructions; the epilogue of a 256x256 c_fc tile was VALU-bound on it: ~25 instructions per element):
+//   gelu  = x s                      gelu' = s (1 + x (1 - s) (2C + 6CK x^2))
+// EXACT (fp32 kernels, decode) keeps the textbook form on tanhf for parity with the oracle.
+#define GELU_W1 (-2.0f * GELU_C * 1.4426950408889634f)      // exp(-2u) = exp2(x (W1 + W2 x^2))
+#define GELU_W2 (GELU_W1 * GELU_K)
+__device__ __forceinline__ float gelu_sig(float x) {
+    const float w = x * (GELU_W1 + GELU_W2 * (x * x));
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
+}
 template <bool EXACT> __device__ __forceinline__ float gelu_f(float x) {
-    float t = tanh_f<EXACT>(GELU_C * (x + GELU_K * x * x * x));
-    return 0.5f * x * (1.0f + t);
+    if (EXACT) {
+        float t = tanh_f<true>(GELU_C * (x + GELU_K * x * x * x));
+        return 0.5f * x * (1.0f + t);
+    }
+    return x * gelu_sig(x);
 }
 template <bool EXACT> __device__ __forceinline__ float gelu_grad_f(float x) {
-    float t = tanh_f<EXACT>(GELU_C * (x + GELU_K * x * x * x));
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * GELU_C * (1.0f + 3.0f * GELU_K * x * x);
+    if (EXACT) {
+        float t = tanh_f<true>(GELU_C * (x + GELU_K * x * x * x));
+        return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * GELU_C * (1.0f + 3.0f * GELU_K * x * x);
+    }
+    const float sg = gelu_sig(x);
+    return sg * (1.0f + x * (1.0f - sg) * (2.0f * GELU_C + 6.0f * GELU_C * GELU_K * (x * x)));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -23,6 +23,7 @@ __global__ void embed_fwd_kernel(const int32_t* __restrict__ ids, const float* _
         const float* a = wte + (int64_t)id * E + e0;
         const float* p = wpe + (int64_t)(pos0 + t) * E + e0;
         Vec16<T> r;
+        const uint32_t rowh = drop_row_hash(drop, (uint32_t)tok);
 #pragma unroll
         for (int i = 0; i < VN; i += 4) {
             f32x4 av = *reinterpret_cast<const f32x4*>(a + i);
@@ -30,7 +31,7 @@ __global__ void embed_fwd_kernel(const int32_t* __restrict__ ids, const float* _
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = av[j] + pv[j];
-                v = apply_drop(drop, (uint64_t)tok * E + e0 + i + j, v);
+                if (drop.thr) v = apply_drop_rc(drop, rowh, (uint32_t)(e0 + i + j), v);
                 r.set(i + j, v);
             }
         }
@@ -51,7 +52,7 @@ __global__ void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __res
     for (int b = 0; b < B; b++) {
         int tok = b * T_ + t;
         float v = to_f32<T>(dh[(int64_t)tok * E + e]);
-        v = apply_drop(drop, (uint64_t)tok * E + e, v);
+        v = apply_drop(drop, (uint32_t)tok, (uint32_t)e, v);
         acc += v;
         atomicAdd(dwte + (int64_t)ids[tok] * E + e, v);
     }
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
         s1 = wave_sum(s1) / (float)E;
         s2 = wave_sum(s2) / (float)E;
+        const uint32_t rowh = drop_row_hash(drop, (uint32_t)row);        // one full hash per row
 #pragma unroll
         for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     o.set(j, v);
                     if (want_colsum) {
                         // the consumer sees the STORED (rounded) value
-                        float vm = apply_drop(drop, (uint64_t)row * E + c * VN + j, o.get(j));
+                        float vm = drop.thr ? apply_drop_rc(drop, rowh, (uint32_t)(c * VN + j), o.get(j)) : o.get(j);
                         om.set(j, vm);
                         cs[i][j] += om.get(j);
                     }

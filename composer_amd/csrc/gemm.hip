@@ -44,7 +44,7 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, void* C, int 
     } else if (ep.act == 2) {
         v *= gelu_grad_f<EXACT>(to_f32<T>(((const T*)ep.aux)[(int64_t)row * ep.ldaux + col]));
     }
-    v = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col, v);
+    v = apply_drop(ep.drop, (uint32_t)row, (uint32_t)col, v);
     if (ep.resid) v += to_f32<T>(((const T*)ep.resid)[(int64_t)row * ep.ldr + col]);
     if (ep.out_fp32) ((float*)C)[(int64_t)row * ldc + col] = v;
     else ((T*)C)[(int64_t)row * ldc + col] = from_f32<T>(v);
@@ -328,8 +328,9 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& ep, void* C, int
         for (int j = 0; j < 4; j++) v[j] *= gelu_grad_f<false>((float)a[j]);
     }
     if (ep.drop.thr) {
+        const uint32_t rh = drop_row_hash(ep.drop, (uint32_t)row);
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+        for (int j = 0; j < 4; j++) v[j] = apply_drop_rc(ep.drop, rh, (uint32_t)(col + j), v[j]);
     }
     if (ep.resid) {
         bf16x4 r = *reinterpret_cast<const bf16x4*>((const bf16_t*)ep.resid + (int64_t)row * ep.ldr + col);
@@ -375,8 +376,9 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& ep, void* C, int
         for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)a[j]);
     }
     if (ep.drop.thr) {
+        const uint32_t rh = drop_row_hash(ep.drop, (uint32_t)row);
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+        for (int j = 0; j < 8; j++) v[j] = apply_drop_rc(ep.drop, rh, (uint32_t)(col + j), v[j]);
     }
     if (ep.resid) {
         bf16x8 r = *reinterpret_cast<const bf16x8*>((const bf16_t*)ep.resid + (int64_t)row * ep.ldr + col);
@@ -451,8 +453,9 @@ __device__ __forceinline__ void epi_finish8(const Epilogue& ep, void* C, int ldc
         for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)in.v[j]);
     }
     if (ep.drop.thr) {
+        const uint32_t rh = drop_row_hash(ep.drop, (uint32_t)row);
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+        for (int j = 0; j < 8; j++) v[j] = apply_drop_rc(ep.drop, rh, (uint32_t)(col + j), v[j]);
     }
     if (ep.resid) {
         if (ep.act == 2) {      // not used by the model: fall back to an in-place load
@@ -563,8 +566,9 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
             for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)opnd[c][j]);
         } else if (KIND == EPI_RESID) {
             if (ep.drop.thr) {
+                const uint32_t rh = drop_row_hash(ep.drop, (uint32_t)row);
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = apply_drop(ep.drop, (uint64_t)row * (uint64_t)ldc + col + j, v[j]);
+                for (int j = 0; j < 8; j++) v[j] = apply_drop_rc(ep.drop, rh, (uint32_t)(col + j), v[j]);
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] += (float)opnd[c][j];
@@ -1017,6 +1021,16 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             nstamp++;
         }
     };
+#ifdef CMP_AB_PHASE     // A/B arm (tools/ab_build.py): every other workgroup of an XCD starts CMP_AB_PHASE cycles late
+#ifdef CMP_AB_PHASE_HALF
+    if (blockIdx.x >= gridDim.x / 2) {
+#else
+    if ((blockIdx.x >> 3) & 1) {
+#endif
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)(CMP_AB_PHASE)) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     int m0, n0, kt0, kt1;
     item_coords(item, m0, n0, kt0, kt1);
     stamp(1);
@@ -1038,6 +1052,25 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             }
         }
         p_glds<B_KM>(rb, lds0 + buf * STAGE + A_IMG, ldb * 2, kt * P_BK, wave * B_PER, B_PER, lane);
+    };
+    // one of this wave's DPS pieces of a stage (the main loop spreads them over the MFMA groups after the barrier: all
+    // 32 pieces of a stage issued back to back right behind the barrier cost ~470 cycles of idle MFMA pipe per k-step --
+    // 32 KiB through the 64 B/clk address path -- measured with the in-kernel stamps)
+    auto issue_piece = [&](int kt, int buf, int j) {
+        if (j < A_PER) {
+            if constexpr (A_KM) {
+                p_glds<true>(ra, lds0 + buf * STAGE, lda * 2, kt * P_BK, wave * A_PER + j, 1, lane);
+            } else {
+                const int p = wave * A_PER + j;
+                constexpr int KPP = 1024 / A_ROWB;
+                constexpr int CPR = A_ROWB / 16;
+                const int k = KPP * p + lane / CPR;
+                const int c = (lane % CPR) ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1);
+                dma16(ra, lds0 + buf * STAGE + p * 1024, (kt * P_BK + k) * lda * 2 + c * 16);
+            }
+        } else {
+            p_glds<B_KM>(rb, lds0 + buf * STAGE + A_IMG, ldb * 2, kt * P_BK, wave * B_PER + (j - A_PER), 1, lane);
+        }
     };
 #pragma unroll
     for (int i = 0; i < AHEAD; i++)
@@ -1077,6 +1110,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             const char* nia = smem + ((t + 1) % NST) * STAGE;
             bf16x8 fa[8], fbn[4], fa0n;
             fa[0] = fa0;
+            bool do_issue = false;
             auto sync_point = [&]() {
                 // stage t+1 must have landed; stages t+2 .. t+AHEAD-1 may still fly.  Past this barrier every wave has
                 // finished stage t-1, so its buffer takes stage t+AHEAD.
@@ -1085,7 +1119,11 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                 stamp(11);
                 __builtin_amdgcn_s_barrier();
                 stamp(12);
+#ifdef CMP_AB_BURST
                 if (t + AHEAD < n) issue(kt0 + t + AHEAD, (t + AHEAD) % NST);
+#else
+                do_issue = t + AHEAD < n;
+#endif
                 stamp(13);
                 if (t + 1 < n) {
 #pragma unroll
@@ -1098,6 +1136,17 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             for (int i = 0; i < 8; i++) {
                 if (i < 7) fa[i + 1] = p_frag<A_KM, A_ROWB>(ia, wm * 8 + i + 1, lane);
                 if (i == bar_at) sync_point();
+                {
+                    // the stage-(t+AHEAD) pieces ride on the MFMA groups behind the barrier
+                    constexpr int NG = 7 - bar_at > 4 ? 4 : 7 - bar_at;          // groups used: 4
+                    constexpr int PPG = (DPS + NG - 1) / NG;
+                    const int g = i - (bar_at + 1);
+                    if (g >= 0 && g < NG && do_issue) {
+#pragma unroll
+                        for (int q = 0; q < PPG; q++)
+                            if (g * PPG + q < DPS) issue_piece(kt0 + t + AHEAD, (t + AHEAD) % NST, g * PPG + q);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -1224,7 +1273,7 @@ static void launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
     }
     const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, BM);
     const int grid = std::min(ntiles * nsplit, NWM == 1 ? 512 : 256);
-    if constexpr (A_KM && !B_KM && NWM == 2 && NST == 4) {
+    if constexpr (A_KM && !B_KM) {
         // the forward layout carries the compile-time epilogue kinds (and the diagnostic timeline build)
         const int kind = epi_kind_of(ep, M, N, swap, slab_stride != 0);
         auto go = [&](auto kern) {
@@ -1232,9 +1281,13 @@ static void launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
             kern<<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, slab_stride, g_gemm_stamps);
         };
         if (g_gemm_stamps && swap) {
-            if (kind == EPI_PLAIN) go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_PLAIN>);
-            else go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_GENERIC>);
-            return;
+            if constexpr (NWM == 2) {
+                if (kind == EPI_PLAIN) go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_PLAIN>);
+                else if (kind == EPI_GELU_AUX) go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_GELU_AUX>);
+                else if (kind == EPI_RESID) go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_RESID>);
+                else go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, true, EPI_GENERIC>);
+                return;
+            }
         }
         if (kind == EPI_PLAIN) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_PLAIN>); return; }
         if (kind == EPI_GELU_AUX) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_GELU_AUX>); return; }

@@ -368,17 +368,18 @@ int ensure_workspace(cmp_model* m, int B, int T) {
 
 // dropout of a gradient tensor (d(dropout(x)) = dy*mask/(1-p)); only launched when the rate is > 0
 template <typename T>
-__global__ void drop_apply_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n, DropCfg d) {
+__global__ void drop_apply_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n, int E, DropCfg d) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = from_f32<T>(apply_drop(d, (uint64_t)i, to_f32<T>(in[i])));
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = from_f32<T>(apply_drop(d, (uint32_t)(i / E), (uint32_t)(i % E), to_f32<T>(in[i])));
 }
 static int drop_apply(cmp_model* m, const void* in, void* out, int64_t n, float p, uint32_t stream_id) {
     DropCfg d = make_drop(p, m->cfg.seed, stream_id);
     int grid = (int)std::min<int64_t>(cdiv64(n, 256), 8192);
     if (m->dtype == CMP_BF16)
-        drop_apply_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)in, (bf16_t*)out, n, d);
+        drop_apply_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)in, (bf16_t*)out, n, m->cfg.embedding_size, d);
     else
-        drop_apply_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)in, (float*)out, n, d);
+        drop_apply_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)in, (float*)out, n, m->cfg.embedding_size, d);
     KERNEL_CHECK();
     return CMP_OK;
 }

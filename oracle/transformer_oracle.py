@@ -65,7 +65,7 @@ def init_params(V, E, W, L, seed=0, mean=0.0, stddev=0.02, dtype=np.float64):
 
 
 # --------------------------------------------------------------------------------------
-# Stateless dropout mask shared bit-for-bit with the HIP kernels (csrc/common.h: keep_mask).
+# Stateless dropout mask shared bit-for-bit with the HIP kernels (csrc/common.h: attn_row_hash / attn_elem_hash / apply_drop).
 # The reference uses tf.nn.dropout (keep-scale 1/(1-p), transformer.py:271-272,361,444,496,506,
 # 681,794); TF's random stream is not reproducible, so both sides use this counter hash.
 # --------------------------------------------------------------------------------------
@@ -80,29 +80,25 @@ def _mix32(x):
     return x
 
 
-def dropout_keep(seed, stream, idx, p):
-    """keep[idx] = hash(seed, stream, idx) >= p * 2^32  (uint32 compare).
-    stream identifies (step, layer, site); idx is the flat element index (uint64, folded)."""
-    idx = np.asarray(idx, dtype=np.uint64)
-    lo = idx & 0xFFFFFFFF
-    hi = idx >> 32
-    h = _mix32(lo ^ np.uint64(seed & 0xFFFFFFFF))
-    h = _mix32(h ^ ((hi * 0x9E3779B1) & 0xFFFFFFFF) ^ np.uint64(stream & 0xFFFFFFFF))
+def dropout_keep_rows(seed, stream, nrows, ncols, p):
+    """Mask [nrows, ncols] (csrc/common.h: attn_row_hash / attn_elem_hash; apply_drop): one full hash per row; the 4
+    columns of a group share the xor base and differ by a 24-bit multiplier:
+        keep[r, c] = (((rowhash(r) ^ ((c >> 2) * 0x9E3779B1)) & 0xFFFFFF) * C24[c & 3]) mod 2^32 >= p * 2^32.
+    Used by every dropout site: rows are tokens (b*T + t) and columns features for the embedding / c_proj / MLP
+    outputs; rows are (batch*head, query) and columns keys for the attention probabilities."""
+    rows = np.arange(nrows, dtype=np.uint64)
+    rowh = _mix32(_mix32(rows ^ np.uint64(seed & 0xFFFFFFFF)) ^ np.uint64(stream & 0xFFFFFFFF))
+    cols = np.arange(ncols, dtype=np.uint64)
+    cq = np.array([0xEBCA6B, 0xB2AE35, 0xD4EB2F, 0x5667B1], dtype=np.uint64)       # 24-bit multipliers
+    x = (rowh[:, None] ^ (((cols >> 2) * 0x9E3779B1) & 0xFFFFFFFF)[None, :]) & 0xFFFFFF
+    x = (x * cq[cols & 3][None, :]) & 0xFFFFFFFF
     thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
-    return h >= thr
+    return x >= thr
 
 
 def dropout_keep_attn(seed, stream, BH, T, p):
-    """Attention-probability mask [BH, T(query), T(key)] (csrc/common.h: attn_row_hash / attn_elem_hash): one full
-    hash per (batch*head, query) row; the 4 keys of a group share the xor base and differ by the multiplier."""
-    rows = np.arange(BH * T, dtype=np.uint64)
-    rowh = _mix32(_mix32(rows ^ np.uint64(seed & 0xFFFFFFFF)) ^ np.uint64(stream & 0xFFFFFFFF))
-    keys = np.arange(T, dtype=np.uint64)
-    cq = np.array([0xEBCA6B, 0xB2AE35, 0xD4EB2F, 0x5667B1], dtype=np.uint64)       # 24-bit multipliers
-    x = (rowh[:, None] ^ (((keys >> 2) * 0x9E3779B1) & 0xFFFFFFFF)[None, :]) & 0xFFFFFF
-    x = (x * cq[keys & 3][None, :]) & 0xFFFFFFFF
-    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
-    return (x >= thr).reshape(BH, T, T)
+    """Attention-probability mask [BH, T(query), T(key)]."""
+    return dropout_keep_rows(seed, stream, BH * T, T, p).reshape(BH, T, T)
 
 
 def dropout_stream(step, layer, site):
@@ -190,8 +186,8 @@ class OracleTransformer:
             keep = dropout_keep_attn(self.seed, dropout_stream(step, layer, site), x.shape[0] * x.shape[1],
                                      x.shape[2], p).reshape(x.shape)
         else:
-            keep = dropout_keep(self.seed, dropout_stream(step, layer, site),
-                                np.arange(x.size, dtype=np.uint64), p).reshape(x.shape)
+            keep = dropout_keep_rows(self.seed, dropout_stream(step, layer, site), x.size // x.shape[-1],
+                                     x.shape[-1], p).reshape(x.shape)
         scale = 1.0 / (1.0 - p)
         m = keep.astype(self.dtype) * scale
         return x * m, m

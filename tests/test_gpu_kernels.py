@@ -147,7 +147,7 @@ def test_gemm_epilogues(lib, dtype, flags):
     assert rel_err(out, A.double() @ B.double() + 1.0) < TOL[dtype]
     # dropout in the epilogue uses the oracle's mask
     out = gemm(lib, dtype, 0, 0, A, B, M, N, K, bias=bias, resid=resid, p_drop=0.25, seed=77, rng=9)
-    keep = O.dropout_keep(77, 9, np.arange(M * N, dtype=np.uint64), 0.25).reshape(M, N)
+    keep = O.dropout_keep_rows(77, 9, M, N, 0.25)
     ref = acc.cpu() * torch.tensor(keep / 0.75) + resid.double().cpu()
     assert rel_err(out, ref) < TOL[dtype]
 
@@ -194,7 +194,7 @@ def test_gemm_epilogue_kinds_full_tiles(lib, tb, M, N, K):
     out, _ = both(resid=resid)                                           # EPI_RESID, no bias (dgrad c_attn)
     assert rel_err(out, acc + resid.double()) < TOL[BF16]
     out, _ = both(bias=bias, resid=resid, p_drop=0.25, seed=77, rng=9)   # EPI_RESID + dropout (oracle's mask)
-    keep = O.dropout_keep(77, 9, np.arange(M * N, dtype=np.uint64), 0.25).reshape(M, N)
+    keep = O.dropout_keep_rows(77, 9, M, N, 0.25)
     assert rel_err(out, accb.cpu() * torch.tensor(keep / 0.75) + resid.double().cpu()) < TOL[BF16]
     out, _ = both(act=2, aux=pre)                                        # EPI_GELUGRAD
     assert rel_err(out, acc.cpu() * torch.tensor(O.gelu_grad(pre.double().cpu().numpy()))) < TOL[BF16]
@@ -256,7 +256,7 @@ def test_layernorm_fwd_bwd(lib, dtype, rows, E):
                                           rows, E, dtype, P(dmask), P(cs), 0.25, 41, 6))
     torch.cuda.synchronize()
     assert torch.equal(dx2, dx)
-    keep = torch.tensor(O.dropout_keep(41, 6, np.arange(rows * E, dtype=np.uint64), 0.25).reshape(rows, E) / 0.75)
+    keep = torch.tensor(O.dropout_keep_rows(41, 6, rows, E, 0.25) / 0.75)
     want = dx.double().cpu() * keep
     assert rel_err(dmask, want) < TOL[dtype]
     assert rel_err(cs, dmask.double().cpu().sum(0) + 2.0) < 3e-5 * math.sqrt(rows) + (0 if dtype == FP32 else 2e-3)
@@ -377,7 +377,7 @@ def test_embedding_fwd_bwd(lib, dtype):
     ids_d, wte_d, wpe_d = dev(ids), dev(wte), dev(wpe)      # keep alive across the launches
     ck(lib, lib.cmp_k_embed_fwd(stream(), P(ids_d), P(wte_d), P(wpe_d), P(out), B, T, E, 0, dtype, 0.3, 5, 2))
     torch.cuda.synchronize()
-    keep = torch.tensor(O.dropout_keep(5, 2, np.arange(B * T * E, dtype=np.uint64), 0.3).reshape(B * T, E) / 0.7)
+    keep = torch.tensor(O.dropout_keep_rows(5, 2, B * T, E, 0.3) / 0.7)
     ref = (wte[ids.long()] + wpe[:T][None]).reshape(B * T, E).double() * keep
     assert rel_err(out, ref) < (1e-6 if dtype == FP32 else 1e-2)
     dh = dev(torch.randn(B * T, E, generator=g), dtype)

@@ -111,10 +111,16 @@ def test_masked_scores_are_exactly_zero_probability():
 
 
 def test_dropout_keep_rate_and_determinism():
-    k = O.dropout_keep(123, O.dropout_stream(1, 2, 3), np.arange(1 << 16, dtype=np.uint64), 0.1)
-    assert abs(k.mean() - 0.9) < 0.01
-    k2 = O.dropout_keep(123, O.dropout_stream(1, 2, 3), np.arange(1 << 16, dtype=np.uint64), 0.1)
-    assert (k == k2).all()
+    # flat sites: [tokens, features] mask -- right rate, deterministic, stream-dependent, no row/column structure
+    k = O.dropout_keep_rows(123, O.dropout_stream(1, 2, 3), 512, 512, 0.1)
+    assert abs(k.mean() - 0.9) < 0.005
+    assert (k == O.dropout_keep_rows(123, O.dropout_stream(1, 2, 3), 512, 512, 0.1)).all()
+    assert (k != O.dropout_keep_rows(123, O.dropout_stream(1, 2, 2), 512, 512, 0.1)).mean() > 0.1
+    assert np.abs(k.mean(axis=0) - 0.9).max() < 0.06 and np.abs(k.mean(axis=1) - 0.9).max() < 0.06
+    assert abs(np.corrcoef(k[:, :-1].ravel(), k[:, 1:].ravel())[0, 1]) < 0.01
+    assert abs(np.corrcoef(k[:-1, :].ravel(), k[1:, :].ravel())[0, 1]) < 0.01
+    for p in (0.25, 0.5):
+        assert abs(O.dropout_keep_rows(9, 77, 256, 768, p).mean() - (1 - p)) < 0.01
     # attention mask: right rate, no row/column structure
     a = O.dropout_keep_attn(7, O.dropout_stream(0, 1, 1), 8, 256, 0.1)
     assert abs(a.mean() - 0.9) < 0.005

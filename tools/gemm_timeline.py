@@ -8,9 +8,15 @@ kb._lib.require_gpu(); torch.zeros(1, device="cuda")
 lib = kb.lib
 B = int(os.environ.get("KB_B", "128"))
 M, N, K = B * 1024, int(os.environ.get("N", "1536")), int(os.environ.get("K", "512"))
+KIND = os.environ.get("KIND", "plain")          # plain | gelu | resid
 A = kb.rnd(M, K); Bm = kb.rnd(K, N); Cm = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16); bias = torch.randn(N, device="cuda")
+aux = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if KIND == "gelu" else None
+res = kb.rnd(M, N) if KIND == "resid" else None
 def run():
-    assert lib.cmp_k_gemm(kb.st(), 1, 0, 0, M, N, K, kb.P(A), K, kb.P(Bm), N, kb.P(Cm), N, kb.P(bias), 0, None, 0, None, 0, 0, 1, 0.0, 0, 0, 16) == 0
+    assert lib.cmp_k_gemm(kb.st(), 1, 0, 0, M, N, K, kb.P(A), K, kb.P(Bm), N, kb.P(Cm), N, kb.P(bias), 1 if KIND == "gelu" else 0,
+                          kb.P(aux) if aux is not None else None, N if aux is not None else 0,
+                          kb.P(res) if res is not None else None, N if res is not None else 0, 0, 1,
+                          0.1 if KIND == "resid" else 0.0, 5, 3, 16) == 0
 for _ in range(3): run()
 buf = torch.zeros(512, device="cuda", dtype=torch.int64)
 lib.cmp_gemm_set_stamps(C.c_void_p(buf.data_ptr()))
