@@ -21,7 +21,20 @@
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+// combine a value with the one on lane ^ 32 (the other 32x32 half): v_permlane32_swap is a VALU instruction, the
+// ds_bpermute shuffle it replaces was an LDS round trip on the softmax critical path.
+__device__ __forceinline__ void both_halves(float v, float& a, float& b) {
+    uint32_t u = __builtin_bit_cast(uint32_t, v), u2 = u;
+    // v_permlane32_swap swaps lanes 32..63 of its first operand with lanes 0..31 of its second, in place:
+    // u -> {lo, lo}, u2 -> {hi, hi}.  (Issued as asm: this hipcc lowers the builtin's SECOND result to the first
+    // operand's register -- checked on hardware with tools/ubench/permlane_test.hip.)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(u2));
+    const uint32_t r[2] = {u, u2};
+    a = __builtin_bit_cast(float, r[0]);
+    b = __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float half_max(float v) { float a, b; both_halves(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float v) { float a, b; both_halves(v, a, b); return a + b; }
 
 template <typename T> struct AT;
 template <> struct AT<bf16_t> {
@@ -92,6 +105,26 @@ template <typename T, int D> struct Stager {
     static constexpr int NC = (64 * CPR + 255) / 256;
     Vec16<T> r[NC];
     __device__ __forceinline__ void load(const T* __restrict__ g, int64_t gstride, int row0, int row_end, int tid) {
+        if constexpr (D >= 32) {
+            // Range-checked buffer loads: rows at or past row_end come back as zeros from the hardware, so the loads are
+            // unconditional straight-line code.  (The guarded global loads they replace sat under divergent branches;
+            // hipcc's wait-count pass then put s_waitcnt vmcnt(1)/vmcnt(0) in front of the first MFMAs of the CURRENT
+            // tile, i.e. every 64-key tile waited for the NEXT tile's HBM round trip: ~3.5k cycles per 32-key
+            // sub-tile instead of ~1k.)
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+            const int64_t span = ((int64_t)(row_end - 1) * gstride + D) * (int64_t)sizeof(T);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)span, 0x00020000);
+            static_assert(64 * CPR == 256 * NC, "whole chunks per thread");
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                const int c = tid + 256 * i;
+                const int row = c / CPR, cc = c % CPR;
+                const int off = (int)(((int64_t)(row0 + row) * gstride + cc * VN) * (int64_t)sizeof(T));
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                r[i].v = __builtin_bit_cast(decltype(r[i].v), w);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NC; i++) {
             const int c = tid + 256 * i;
@@ -296,6 +329,49 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
                 sk.load(kg, rs, kt0 + 64, Tn, tid);
                 sv.load(vg, rs, kt0 + 64, Tn, tid);
             }
+            // Fast path (throughput mode): all 64 keys of the tile are at or below every query of this wave -> no
+            // masking; both 32-key sub-tiles go through ONE softmax step: 8 score MFMAs back to back, one row-max exchange
+            // and one rescale vote per 64 keys, 32 exponentials, 8 PV MFMAs.
+            const bool full64 = !EXACT && (kt0 + 63 <= q0w) && (kt0 + 64 <= Tn);      // wave-uniform
+            if (full64) {
+                f32x16 s0, s1;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
+                s0 = mma_rows<T, D>(Ks, 0, qf, lane, s0);
+                s1 = mma_rows<T, D>(Ks, 32, qf, lane, s1);
+                const float mloc = half_max(fmaxf(max16(s0), max16(s1)));
+                const float mnew = fmaxf(m, mloc);
+                if (!__all(mnew == m)) {
+                    const float alpha = fast_exp2((m - mnew) * c2);
+                    lsum *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+                    m = mnew;
+                }
+                const float mc = m * c2;
+                float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float p0 = fast_exp2(fmaf(s0[r], c2, -mc));
+                    const float p1 = fast_exp2(fmaf(s1[r], c2, -mc));
+                    ps0 += p0;
+                    ps1 += p1;
+                    s0[r] = p0;
+                    s1[r] = p1;
+                }
+                lsum += ps0 + ps1;
+                if constexpr (DROP) {
+                    mask16_qlane(s0, rowh, kt0, h, drop.thr);
+                    mask16_qlane(s1, rowh, kt0 + 32, h, drop.thr);
+                }
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++) {
+                    oacc[dt] = mma_acc_b<T, D>(Vs, 0, dt, s0, lane, oacc[dt]);
+                    oacc[dt] = mma_acc_b<T, D>(Vs, 32, dt, s1, lane, oacc[dt]);
+                }
+            } else
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
                 const int k0 = kt0 + 32 * sub;
@@ -315,7 +391,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
                         s[r] = v;
                         mloc = fmaxf(mloc, v);
                     }
-                    mloc = fmaxf(mloc, xhalf(mloc));
+                    mloc = half_max(mloc);
                     const float mnew = fmaxf(m, mloc);
                     const float alpha = expf(m - mnew);
                     float ps = 0.f;
@@ -343,7 +419,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
                         }
                     }
                     float mloc = max16(s);
-                    mloc = fmaxf(mloc, xhalf(mloc));
+                    mloc = half_max(mloc);
                     const float mnew = fmaxf(m, mloc);
                     if (!__all(mnew == m)) {
                         const float alpha = fast_exp2((m - mnew) * c2);
@@ -378,7 +454,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
             }
             __syncthreads();
         }
-        const float ltot = lsum + xhalf(lsum);
+        const float ltot = half_sum(lsum);
         const float inv = (DROP ? drop.scale : 1.0f) / ltot;
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(og, E, q, qvalid, dt, oacc[dt], inv, h);
@@ -570,17 +646,21 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
 
         Stager<T, D> sq, so;
         float st_l = 0.f, st_d = 0.f;
-        auto load_rows = [&](int qt) {     // per-row scalars of tile qt: threads 0..63
-            if (tid < 64) {
-                const int qq = qt + tid;
-                st_l = qq < Tn ? lse[(int64_t)blockIdx.y * Tn + qq] * (EXACT ? 1.0f : LOG2E_F) : 0.f;
-                st_d = qq < Tn ? delta[(int64_t)blockIdx.y * Tn + qq] / keep_scale : 0.f;
-            }
+        // per-row scalars of tile qt (threads 0..63): raw loads only -- any arithmetic on the loaded value here would make
+        // the compiler wait for it (and for the tile loads issued before it) ahead of the current tile's MFMAs; the
+        // scale factors are applied in store_rows, after the tile's work.  Rows past Tn read a clamped (finite) row;
+        // their probabilities are masked to zero.
+        // Every wave issues them (same 256 bytes, L1 hits): with the loads under `if (tid < 64)` the wait-count pass
+        // sized the waits in front of the MFMAs for the shorter path and made the other wave stall on a tile load.
+        auto load_rows = [&](int qt) {
+            const int qq = min(qt + (tid & 63), Tn - 1);
+            st_l = lse[(int64_t)blockIdx.y * Tn + qq];
+            st_d = delta[(int64_t)blockIdx.y * Tn + qq];
         };
         auto store_rows = [&](float* dst, int qt) {
             if (tid < 64) {
-                dst[tid] = st_l;
-                dst[64 + tid] = st_d;
+                dst[tid] = st_l * (EXACT ? 1.0f : LOG2E_F);
+                dst[64 + tid] = st_d / keep_scale;
                 reinterpret_cast<uint32_t*>(dst)[128 + tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + qt + tid));
             }
         };
