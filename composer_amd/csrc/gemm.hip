@@ -517,7 +517,10 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
     bf16x8 opnd[16];
     auto fetch = [&](int c) {
         const int row = row0 + (c >> 1) * 16 + (c & 1) * 8 + rl;
-        opnd[c] = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col);
+        // the 4E-wide pre-activation stream (0.5 GB per launch at B=128) is read non-temporally: 408 -> 380 us same-box;
+        // for the E-wide residual the hint measured neutral
+        if (KIND == EPI_GELUGRAD) opnd[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col));
+        else opnd[c] = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col);
     };
     if (LOADS) {
 #pragma unroll
@@ -558,7 +561,9 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
             bf16x8 a;
 #pragma unroll
             for (int j = 0; j < 8; j++) a[j] = (bf16_t)v[j];
-            *reinterpret_cast<bf16x8*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col) = a;
+            // streamed once, consumed by a later kernel: non-temporal, so the tile does not evict the A panels and the
+            // weight matrix from this XCD's 4 MiB L2 (same-box A/B: c_fc 470 -> 408 us, c_attn 306 -> 279 us)
+            __builtin_nontemporal_store(a, reinterpret_cast<bf16x8*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col));
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = gelu_f<false>(v[j]);
         } else if (KIND == EPI_GELUGRAD) {
@@ -576,7 +581,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = (bf16_t)v[j];
-        *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col));
     }
 }
 // the kind a launch may use (full tiles only; everything else takes the generic run-time epilogue)
