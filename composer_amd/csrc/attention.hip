@@ -274,6 +274,21 @@ __device__ __forceinline__ int pair_block(int ph, int nb, int x) {
     return x < hi ? x : -1;
 }
 
+// XCD-aware block mapping: consecutive workgroup ids go to different XCDs (id mod 8), so the gridDim.x workgroups
+// that share one (batch, head)'s K/V (Q/dO) would land on different L2s.  Re-deal: XCD x takes (batch, head) rows
+// x, x+8, ... and runs the gridDim.x blocks of a row on consecutive slots -> one L2 serves the row's tile re-reads.
+__device__ __forceinline__ void xcd_block(int& bx, int& by) {
+#ifdef CMP_AB_NOXCD
+    bx = blockIdx.x; by = blockIdx.y; return;
+#endif
+    const int gx = gridDim.x, gy = gridDim.y;
+    if (gy & 7) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const int L = blockIdx.x + gx * blockIdx.y;          // dispatch order: x fastest
+    const int xcd = L & 7, slot = L >> 3;
+    bx = slot % gx;
+    by = (slot / gx) * 8 + xcd;
+}
+
 // =================================================================================================
 // forward.  grid ((nb+1)/2, B*H), 256 threads: wave w owns query rows [qb*128 + 32w, +32)
 // =================================================================================================
@@ -288,7 +303,9 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
     constexpr int IMG = 64 * G::S;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y / H, hd = blockIdx.y % H;
+    int bx, by;
+    xcd_block(bx, by);
+    const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;                        // row stride of qkv
     const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
     const int nb = cdiv(Tn, 128);
 
     for (int ph = 0; ph < 2; ph++) {
-        const int qb = pair_block(ph, nb, blockIdx.x);
+        const int qb = pair_block(ph, nb, bx);
         if (qb < 0) break;
         const int q0w = qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
             for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
         float m = -INFINITY, lsum = 0.f;   // running max: scaled domain (parity mode) / raw domain (throughput mode)
         const int kv_end = min(Tn, qb * 128 + 128);
-        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
 
         Stager<T, D> sk, sv;
         sk.load(kg, rs, 0, Tn, tid);
@@ -458,7 +475,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
         const float inv = (DROP ? drop.scale : 1.0f) / ltot;
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(og, E, q, qvalid, dt, oacc[dt], inv, h);
-        if (qvalid && h == 0) lse[(int64_t)blockIdx.y * Tn + q] = (EXACT ? m : m * scale) + logf(ltot);
+        if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = (EXACT ? m : m * scale) + logf(ltot);
     }
 }
 
@@ -505,7 +522,9 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T
     constexpr int IMG = 64 * G::S;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y / H, hd = blockIdx.y % H;
+    int bx, by;
+    xcd_block(bx, by);
+    const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
     const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T
     const int nb = cdiv(Tn, 128);
 
     for (int ph = 0; ph < 2; ph++) {
-        const int qb = pair_block(ph, nb, blockIdx.x);
+        const int qb = pair_block(ph, nb, bx);
         if (qb < 0) break;
         const int q0w = qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
@@ -526,8 +545,8 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T
         frag_t<T> qf[G::NS], dof[G::NS];
         load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
         load_bfrags<T, D>(dof, dog, E, q, qvalid, h);
-        const float lse_q = qvalid ? lse[(int64_t)blockIdx.y * Tn + q] : 0.f;
-        const float del_q = (qvalid ? delta[(int64_t)blockIdx.y * Tn + q] : 0.f) / keep_scale;
+        const float lse_q = qvalid ? lse[(int64_t)by * Tn + q] : 0.f;
+        const float del_q = (qvalid ? delta[(int64_t)by * Tn + q] : 0.f) / keep_scale;
         const float lse2 = lse_q * LOG2E_F;
         f32x16 dq[G::DT];
 #pragma unroll
@@ -535,7 +554,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T
 #pragma unroll
             for (int r = 0; r < 16; r++) dq[dt][r] = 0.f;
         const int kv_end = min(Tn, qb * 128 + 128);
-        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + q));
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
 
         Stager<T, D> sk, sv;
         sk.load(kg, rs, 0, Tn, tid);
@@ -613,7 +632,9 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
     float* Lb = reinterpret_cast<float*>(Qb + 4 * IMG);     // 2 x { lse [64] | delta/f [64] | dropout row hash [64] }
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y / H, hd = blockIdx.y % H;
+    int bx, by;
+    xcd_block(bx, by);
+    const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
     const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
@@ -628,7 +649,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
 
     for (int ph = 0; ph < 2; ph++) {
         // light/heavy are mirrored w.r.t. the forward: key block 0 is the heavy one
-        const int kb = ph == 0 ? (int)blockIdx.x : ((int)blockIdx.x < nb - 1 - (int)blockIdx.x ? nb - 1 - (int)blockIdx.x : -1);
+        const int kb = ph == 0 ? bx : (bx < nb - 1 - bx ? nb - 1 - bx : -1);
         if (kb < 0) break;
         const int k0w = kb * 128 + wave * 32;
         const int key = k0w + (lane & 31);
@@ -654,14 +675,14 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
         // sized the waits in front of the MFMAs for the shorter path and made the other wave stall on a tile load.
         auto load_rows = [&](int qt) {
             const int qq = min(qt + (tid & 63), Tn - 1);
-            st_l = lse[(int64_t)blockIdx.y * Tn + qq];
-            st_d = delta[(int64_t)blockIdx.y * Tn + qq];
+            st_l = lse[(int64_t)by * Tn + qq];
+            st_d = delta[(int64_t)by * Tn + qq];
         };
         auto store_rows = [&](float* dst, int qt) {
             if (tid < 64) {
                 dst[tid] = st_l * (EXACT ? 1.0f : LOG2E_F);
                 dst[64 + tid] = st_d / keep_scale;
-                reinterpret_cast<uint32_t*>(dst)[128 + tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(blockIdx.y * Tn + qt + tid));
+                reinterpret_cast<uint32_t*>(dst)[128 + tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + qt + tid));
             }
         };
         const int qstart = kb * 128;
