@@ -71,6 +71,7 @@ SIGNATURES = {
     "cmp_k_layernorm_bwd_fused": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _P, _f, _u64, _u32]),
     "cmp_k_gemm": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _i, _i, _f, _u64, _u32, _i]),
     "cmp_gemm_set_workspace": (_i, [_P, _i64]),
+    "cmp_gemm_colsum_next": (_i, [_P]),
     "cmp_gemm_set_stamps": (_i, [_P]),
     "cmp_k_colsum": (_i, [_P, _P, _i, _P, _i, _i, _i]),
     "cmp_k_attn_fwd": (_i, [_P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _f, _u64, _u32]),

@@ -442,9 +442,13 @@ static int loss(cmp_model* m, const int32_t* y_dev, int M, bool want_grad) {
 }
 
 static int wgrad_splits(int K, int M, int N) {
-    // contraction over tokens: make ~512+ workgroups
-    int tiles = cdiv(M, 128) * cdiv(N, 128);
-    int s = std::max(1, 768 / std::max(1, tiles));
+    // contraction over tokens.  The persistent kernel works on 256x256 tiles x splits: with 8+ tiles, one item per CU
+    // (256 CUs) -- every extra split is another round of f32 atomics on the same addresses (measured at K=131072:
+    // 16 splits 298 us, 32 splits 369 us for the 2048x512 wgrad).  Few tiles: more splits than CUs/tiles only cost.
+    const int tiles256 = cdiv(M, 256) * cdiv(N, 256);
+    int s;
+    if (tiles256 >= 8) s = std::max(1, 256 / tiles256);
+    else s = std::max(1, 768 / std::max(1, cdiv(M, 128) * cdiv(N, 128)));
     return std::min(s, std::max(1, K / 256));
 }
 
@@ -488,11 +492,11 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         CHECK_RC(gemm(m, 1, 0, 4 * E, E, M, a.g, 4 * E, dmo, E, m->G + o.pr_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, 4 * E, E)), 0.f, 0));
         if (!dmo_ready) CHECK_RC(cmp_k_colsum(s, dmo, E, m->G + o.pr_b, M, E, dt));
+        CHECK_RC(cmp_gemm_colsum_next(m->G + o.fc_b));                             // b_fc grad = column sums of dfc
         CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, dmo, E, m->w(o.pr_w), E, m->dfc, 4 * E, nullptr, 2, a.fc, 4 * E, nullptr, 0, 0, 1,
                       0.f, 0));                                                    // dfc = (dmo.Wpr^T) * gelu'(fc)
         CHECK_RC(gemm(m, 1, 0, E, 4 * E, M, a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, E, 4 * E)), 0.f, 0));
-        CHECK_RC(cmp_k_colsum(s, m->dfc, 4 * E, m->G + o.fc_b, M, 4 * E, dt));
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr,
                           0, 0, 1, 0.f, 0));                                       // dn

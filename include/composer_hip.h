@@ -170,6 +170,10 @@ int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
  * fold them in a fixed order (reproducible, no float atomics); without it (or if too small: splitk*M*N*4 bytes) they
  * accumulate with f32 atomics.  flags & 128 forces the atomic path. */
 int cmp_gemm_set_workspace(void* ws_dev, int64_t bytes);
+/* One-shot: the next cmp_k_gemm (plain output in the compute dtype) also adds the column sums of its output to
+ * out[0..N) -- the bias gradient that goes with an input-gradient GEMM (transformer.py:916-920 via tf.GradientTape).
+ * Fused into the GEMM epilogue where possible, otherwise a cmp_k_colsum pass after it. */
+int cmp_gemm_colsum_next(float* out);
 /* diagnostic only: a device buffer of 500 uint64 receives (id, s_memtime) pairs from one workgroup of the next
  * deep-pipeline GEMM launches (tools/gemm_timeline.py); pass NULL to switch it off. */
 int cmp_gemm_set_stamps(void* dev_buf);

@@ -200,6 +200,24 @@ def test_gemm_epilogue_kinds_full_tiles(lib, tb, M, N, K):
     assert rel_err(out, acc.cpu() * torch.tensor(O.gelu_grad(pre.double().cpu().numpy()))) < TOL[BF16]
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(512, 512, 256, 1), (1024, 768, 128, 0), (136, 264, 128, 1)])
+def test_gemm_fused_column_sums(lib, M, N, K, tb):
+    """cmp_gemm_colsum_next: the next GEMM also accumulates the column sums of its STORED bf16 output into an fp32
+    vector (bias gradient) -- fused into the compile-time epilogues (full 256-tiles) or via a colsum pass (ragged)."""
+    g = torch.Generator().manual_seed(M + N)
+    a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) * 0.2
+    A, B = dev(a, BF16), dev(b.t().contiguous() if tb else b, BF16)
+    pre = dev(torch.randn(M, N, generator=g), BF16)
+    for kw in (dict(), dict(act=2, aux=pre)):
+        out_vec = torch.full((N,), 3.0, device="cuda")
+        ck(lib, lib.cmp_gemm_colsum_next(P(out_vec)))
+        out = gemm(lib, BF16, 0, tb, A, B, M, N, K, **kw)
+        ref = out.double().sum(0) + 3.0
+        assert rel_err(out_vec, ref) < 1e-5
+        again = gemm(lib, BF16, 0, tb, A, B, M, N, K, **kw)            # one-shot: the next launch does not touch it
+        assert torch.equal(out, again) and rel_err(out_vec, ref) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [FP32, BF16])
 @pytest.mark.parametrize("flags", [4, 8, 16, 48, 16 | 128])
 def test_gemm_wgrad_shape_large_k(lib, dtype, flags):

@@ -72,8 +72,11 @@ def bench_gemm():
     tot += gemm_case("dgrad attn c_proj", 0, 1, M, E, E)
     tot += gemm_case("dgrad c_attn (+resid)", 0, 1, M, E, 3 * E, resid=True)
     for nm, m, n in (("wgrad mlp c_proj", 4 * E, E), ("wgrad c_fc", E, 4 * E), ("wgrad attn c_proj", E, E), ("wgrad c_attn", E, 3 * E)):
-        tiles = ((m + 127) // 128) * ((n + 127) // 128)
-        s = max(2, min(max(1, 768 // tiles), 32768 // 256))
+        # model.hip::wgrad_splits
+        t256 = ((m + 255) // 256) * ((n + 255) // 256)
+        t128 = ((m + 127) // 128) * ((n + 127) // 128)
+        s = max(1, 256 // t256) if t256 >= 8 else max(1, 768 // t128)
+        s = max(2, min(s, M // 256))
         tot += gemm_case(nm, 1, 0, m, n, M, splitk=s, out_fp32=True)
     print("sum of the 12 per-layer GEMMs: %.1f us  (%.1f TFLOP/s average)" % (tot, 3 * 2.0 * M * 12 * E * E / tot / 1e6))
 
