@@ -278,9 +278,6 @@ __device__ __forceinline__ int pair_block(int ph, int nb, int x) {
 // that share one (batch, head)'s K/V (Q/dO) would land on different L2s.  Re-deal: XCD x takes (batch, head) rows
 // x, x+8, ... and runs the gridDim.x blocks of a row on consecutive slots -> one L2 serves the row's tile re-reads.
 __device__ __forceinline__ void xcd_block(int& bx, int& by) {
-#ifdef CMP_AB_NOXCD
-    bx = blockIdx.x; by = blockIdx.y; return;
-#endif
     const int gx = gridDim.x, gy = gridDim.y;
     if (gy & 7) { bx = blockIdx.x; by = blockIdx.y; return; }
     const int L = blockIdx.x + gx * blockIdx.y;          // dispatch order: x fastest

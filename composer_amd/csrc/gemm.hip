@@ -946,6 +946,11 @@ __device__ __forceinline__ v4i32 make_srd(const void* base, int64_t bytes) {
 // would put s_waitcnt vmcnt(0) in front of the next ds_read and drain the pipeline).  M0 (LDS base) is written in
 // the same statement that reads it; completion is tracked by hand with counted s_waitcnt vmcnt(N).
 __device__ __forceinline__ void dma16(v4i32 srd, uint32_t lds_addr, int voff) {
+    // the "s" operands must BE in SGPRs: after control-flow merges the compiler may carry wave-uniform values in VGPRs
+    // and does not legalise inline-asm operands (readfirstlane folds away when the value already lives in an SGPR)
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+#pragma unroll
+    for (int i = 0; i < 4; i++) srd[i] = __builtin_amdgcn_readfirstlane(srd[i]);
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(srd)
@@ -1045,16 +1050,6 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             nstamp++;
         }
     };
-#ifdef CMP_AB_PHASE     // A/B arm (tools/ab_build.py): every other workgroup of an XCD starts CMP_AB_PHASE cycles late
-#ifdef CMP_AB_PHASE_HALF
-    if (blockIdx.x >= gridDim.x / 2) {
-#else
-    if ((blockIdx.x >> 3) & 1) {
-#endif
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)(CMP_AB_PHASE)) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     int m0, n0, kt0, kt1;
     item_coords(item, m0, n0, kt0, kt1);
     stamp(1);
@@ -1143,11 +1138,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                 stamp(11);
                 __builtin_amdgcn_s_barrier();
                 stamp(12);
-#ifdef CMP_AB_BURST
-                if (t + AHEAD < n) issue(kt0 + t + AHEAD, (t + AHEAD) % NST);
-#else
                 do_issue = t + AHEAD < n;
-#endif
                 stamp(13);
                 if (t + 1 < n) {
 #pragma unroll
@@ -1316,6 +1307,13 @@ static bool launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
         if (kind == EPI_PLAIN) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_PLAIN>); return true; }
         if (kind == EPI_GELU_AUX) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_GELU_AUX>); return true; }
         if (kind == EPI_RESID) { go(gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST, false, EPI_RESID>); return true; }
+    }
+    if constexpr (!A_KM && !B_KM && NWM == 2) {
+        if (g_gemm_stamps && !swap) {        // diagnostic timeline of the wgrad layout (split-K atomics epilogue)
+            allow_smem((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST, true>, smem);
+            gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST, true><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, (int64_t)0, g_gemm_stamps);
+            return false;
+        }
     }
     if (swap)
         gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST><<<grid, 256 * NWM, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles, slab_stride, g_gemm_stamps);

@@ -8,11 +8,19 @@ kb._lib.require_gpu(); torch.zeros(1, device="cuda")
 lib = kb.lib
 B = int(os.environ.get("KB_B", "128"))
 M, N, K = B * 1024, int(os.environ.get("N", "1536")), int(os.environ.get("K", "512"))
-KIND = os.environ.get("KIND", "plain")          # plain | gelu | resid
+KIND = os.environ.get("KIND", "plain")          # plain | gelu | resid | wgrad (C[M,N] += A[K,M]^T B[K,N], split-K atomics)
 A = kb.rnd(M, K); Bm = kb.rnd(K, N); Cm = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16); bias = torch.randn(N, device="cuda")
 aux = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if KIND == "gelu" else None
 res = kb.rnd(M, N) if KIND == "resid" else None
+WG = KIND == "wgrad"
+if WG:
+    Mw, Nw, Kw = int(os.environ.get("M", "512")), N, B * 1024
+    A = kb.rnd(Kw, Mw); Bm = kb.rnd(Kw, Nw); Cm = torch.zeros(Mw, Nw, device="cuda")
+    SPL = int(os.environ.get("SPLITK", "16"))
 def run():
+    if WG:
+        assert lib.cmp_k_gemm(kb.st(), 1, 1, 0, Mw, Nw, Kw, kb.P(A), Mw, kb.P(Bm), Nw, kb.P(Cm), Nw, None, 0, None, 0, None, 0, 1, SPL, 0.0, 0, 0, 16) == 0
+        return
     assert lib.cmp_k_gemm(kb.st(), 1, 0, 0, M, N, K, kb.P(A), K, kb.P(Bm), N, kb.P(Cm), N, kb.P(bias), 1 if KIND == "gelu" else 0,
                           kb.P(aux) if aux is not None else None, N if aux is not None else 0,
                           kb.P(res) if res is not None else None, N if res is not None else 0, 0, 1,
