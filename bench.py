@@ -32,13 +32,26 @@ PEAK_HBM_GBS = 8000.0
 KERNEL_CLASSES = {
     0: ("gemm_bf16_p4_kernel<A[M,K],B[K,N]> (forward Conv1D: c_attn/c_proj/c_fc/mlp c_proj, tied logits)", "mfma"),
     1: ("gemm_bf16_256_kernel<B stored [N,K]> (dgrad)", "mfma"),
-    2: ("gemm_bf16_p4_kernel<A stored [K,M]> (wgrad, split-K slabs)", "mfma"),
+    2: ("gemm_bf16_p4_kernel<A stored [K,M]> (wgrad, split-K f32 atomics)", "mfma"),
     3: ("attn_fwd_kernel<bf16,64>", "mfma"),
     4: ("attn_dq_kernel<bf16,64>", "mfma"),
     5: ("attn_dkv_kernel<bf16,64>", "mfma"),
     6: ("layernorm_fwd_kernel<bf16>", "hbm"),
     7: ("adam_kernel", "hbm"),
 }
+
+
+def pmc_traffic(kernel_class, batch):
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/hbm_traffic.json, made by
+    tools/profile_round.sh + tools/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, gfx950
+    correction applied).  Counters cannot be read from inside this process; None when the file does not cover the run."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    except Exception:
+        return None
+    if kernel_class != 0 or batch * T != doc.get("tokens_per_launch"):
+        return None
+    return doc.get("class0_forward_gemm_mean_bytes_per_launch")
 
 
 def flops_per_token_train():
@@ -179,7 +192,10 @@ def main():
             if bound == "mfma":
                 achieved = work.value / (ms.value * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None}
+                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args.roofline_kernel, Bq)}
+                if roof["traffic"] is not None:
+                    roof["traffic_note"] = ("HBM-side bytes per launch (mean of the four per-layer forward GEMMs), rocprofv3 PMC "
+                                            "FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json; algorithmic bytes 740 MB")
             else:
                 achieved = work.value / (ms.value * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -312,21 +312,33 @@ __global__ void softmax_xent_kernel(const float* __restrict__ z, int ldz, const 
     }
 }
 
-// deterministic single-workgroup reduction of the per-row losses
-__global__ void metrics_reduce_kernel(const float* __restrict__ row_loss, const int32_t* __restrict__ row_correct,
-                                      int rows, Metrics* __restrict__ out) {
-    __shared__ double sl[256];
-    __shared__ long long sc[256];
-    double a = 0.0;
-    long long c = 0;
-    for (int i = threadIdx.x; i < rows; i += 256) {
-        a += (double)row_loss[i];
+// deterministic single-workgroup reduction of the per-row losses (fixed summation order: 1024 threads, 16-byte loads,
+// four independent partial sums per thread; the 256-thread scalar loop it replaces took 142 us at 131072 rows)
+__global__ __launch_bounds__(1024) void metrics_reduce_kernel(const float* __restrict__ row_loss, const int32_t* __restrict__ row_correct,
+                                                               int rows, Metrics* __restrict__ out) {
+    __shared__ double sl[1024];
+    __shared__ long long sc[1024];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = 0;
+    const int rows4 = rows >> 2;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int i = threadIdx.x; i < rows4; i += 1024) {
+        const f32x4 l = reinterpret_cast<const f32x4*>(row_loss)[i];
+        const i32x4 k = reinterpret_cast<const i32x4*>(row_correct)[i];
+        a0 += (double)l[0];
+        a1 += (double)l[1];
+        a2 += (double)l[2];
+        a3 += (double)l[3];
+        c += k[0] + k[1] + k[2] + k[3];
+    }
+    for (int i = (rows4 << 2) + threadIdx.x; i < rows; i += 1024) {
+        a0 += (double)row_loss[i];
         c += row_correct[i];
     }
-    sl[threadIdx.x] = a;
+    sl[threadIdx.x] = (a0 + a1) + (a2 + a3);
     sc[threadIdx.x] = c;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             sl[threadIdx.x] += sl[threadIdx.x + s];
             sc[threadIdx.x] += sc[threadIdx.x + s];
@@ -541,7 +553,7 @@ extern "C" int cmp_k_softmax_xent(void* stream, const float* logits, int ldz, co
 }
 
 int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics) {
-    metrics_reduce_kernel<<<1, 256, 0, s>>>(row_loss, row_correct, rows, (Metrics*)metrics);
+    metrics_reduce_kernel<<<1, 1024, 0, s>>>(row_loss, row_correct, rows, (Metrics*)metrics);
     KERNEL_CHECK();
     return CMP_OK;
 }
