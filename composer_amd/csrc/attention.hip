@@ -477,40 +477,15 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
 }
 
 // =================================================================================================
-// delta[b,h,t] = sum_d dO.O   (rowsum(dP.P))
-// =================================================================================================
-template <typename T>
-__global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ delta,
-                                  int B, int Tn, int H, int D) {
-    // one wave per token row [E = H*D]: lane l owns the 16-byte chunks l, l+64, ...; the D/VN lanes of a head are
-    // adjacent, so a segmented xor-shuffle reduction gives the per-head sums (coalesced 1 KiB reads).
-    constexpr int VN = Vec16<T>::N;
-    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    const int E = H * D, chunks = E / VN, cph = D / VN;          // chunks per head: 2..32 (power of two)
-    for (int64_t row = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); row < (int64_t)B * Tn; row += (int64_t)gridDim.x * wpb) {
-        const int b = (int)(row / Tn), t = (int)(row % Tn);
-        for (int c0 = 0; c0 < chunks; c0 += 64) {
-            const int c = c0 + lane;
-            float a = 0.f;
-            if (c < chunks) {
-                Vec16<T> x = ld16(o + row * E + c * VN), y = ld16(d_o + row * E + c * VN);
-#pragma unroll
-                for (int j = 0; j < VN; j++) a += x.get(j) * y.get(j);
-            }
-            for (int s = 1; s < cph; s <<= 1) a += __shfl_xor(a, s);
-            if (c < chunks && (c % cph) == 0) delta[((int64_t)b * H + c / cph) * Tn + t] = a;
-        }
-    }
-}
-
-// =================================================================================================
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
 // With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
 // =================================================================================================
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW))
+void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                                         const T* __restrict__ d_o,
                                                                          const float* __restrict__ lse,
-                                                                         const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                                         float* __restrict__ delta, T* __restrict__ dqkv,
                                                                          int Tn, int H, float scale, DropCfg drop) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
@@ -543,7 +518,11 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T
         load_bfrags<T, D>(qf, qg, rs, q, qvalid, h);
         load_bfrags<T, D>(dof, dog, E, q, qvalid, h);
         const float lse_q = qvalid ? lse[(int64_t)by * Tn + q] : 0.f;
-        const float del_q = (qvalid ? delta[(int64_t)by * Tn + q] : 0.f) / keep_scale;
+        // delta[q] = rowsum(dO . O) is computed here -- this lane already holds its half of the dO row
+        // -- and stored for the dK/dV kernel that runs next on the stream (this replaced a separate 52 us pass per layer).
+        // The O row is requested now and consumed after the first K/V tile has been staged, under that latency.
+        frag_t<T> of[G::NS];
+        load_bfrags<T, D>(of, o + (int64_t)b * Tn * E + hd * D, E, q, qvalid, h);
         const float lse2 = lse_q * LOG2E_F;
         f32x16 dq[G::DT];
 #pragma unroll
@@ -558,6 +537,19 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dq_kernel(const T
         sv.load(vg, rs, 0, Tn, tid);
         sk.store(Kb, tid);
         sv.store(Kb + IMG, tid);
+        float dsum = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < G::NS; sidx++) {
+            if constexpr (std::is_same<T, float>::value) {
+                dsum += of[sidx] * dof[sidx];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) dsum += (float)of[sidx][j] * (float)dof[sidx][j];
+            }
+        }
+        dsum = half_sum(dsum);
+        if (qvalid && h == 0) delta[(int64_t)by * Tn + q] = dsum;
+        const float del_q = (qvalid ? dsum : 0.f) / keep_scale;
         __syncthreads();
         for (int kt0 = 0, it = 0; kt0 < kv_end; kt0 += 64, it++) {
             const T* Ks = Kb + (it & 1) * 2 * IMG;
@@ -784,8 +776,6 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
 template <typename T, int D>
 static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                       void* dqkv, int B, int Tn, int H, float scale, DropCfg d) {
-    attn_delta_kernel<T><<<(int)std::min<int64_t>(cdiv64((int64_t)B * Tn, 4), 4096), 256, 0, s>>>((const T*)o, (const T*)d_o, delta, B, Tn, H, D);
-    KERNEL_CHECK();
     dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem + 1536 > 65536) {
@@ -796,8 +786,8 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
     }
     const double fl = (double)B * H * (double)Tn * Tn * D;        // one product over the unmasked half
     PROF_START(4, s);
-    if (d.thr) attn_dq_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
-    else attn_dq_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    if (d.thr) attn_dq_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    else attn_dq_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
     PROF_STOP(4, s, 3.0 * fl);
     KERNEL_CHECK();
     PROF_START(5, s);
