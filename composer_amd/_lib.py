@@ -75,6 +75,7 @@ SIGNATURES = {
     "cmp_gemm_set_stamps": (_i, [_P]),
     "cmp_k_colsum": (_i, [_P, _P, _i, _P, _i, _i, _i]),
     "cmp_k_attn_fwd": (_i, [_P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_attn_bwd_bias_next": (_i, [_P]),
     "cmp_k_attn_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_softmax_xent": (_i, [_P, _P, _i, _P, _P, _P, _P, _i, _i, _f, _i]),
     "cmp_k_adam": (_i, [_P, _P, _P, _P, _P, _P, _i64, _f, _f, _f, _f, _i64, _f]),

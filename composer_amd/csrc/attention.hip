@@ -266,6 +266,53 @@ __device__ __forceinline__ void store_t_tile(T* __restrict__ out, int64_t ostrid
     }
 }
 
+// Column sums of a wave's transposed output tiles (Y^T[d][row], 32 rows on the lanes of each half) added to
+// bias_grad[d]: the c_attn bias gradient is the column sum of [dQ | dK | dV] (Conv1D bias under tf.GradientTape,
+// transformer.py:205-209); taking it from the f32 accumulators saves a 63 us re-read of the [M,3E] gradient per layer.
+// Transpose-reduce: 31 shuffles leave lane l (of each half) with the total of value l, then ONE atomic instruction per
+// wave writes 64 distinct columns.  (A first version reduced every value to lane 0 and issued 32 two-lane atomics per
+// tile set: 3 M atomic instructions per layer on 1536 addresses cost 0.8 ms.)
+template <typename T, int D>
+__device__ __forceinline__ void colsum_t_tiles(float* __restrict__ bias_grad, bool valid, const f32x16* y, float mul, int h,
+                                               int lane) {
+    constexpr int DT = Geo<T, D>::DT;
+    const int l = lane & 31;
+#pragma unroll
+    for (int t0 = 0; t0 < DT; t0 += 2) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const bool pair = t0 + 1 < DT;                  // two tiles = 32 values, or a single tile = 16
+        float v[32];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            v[r] = valid ? y[t0][r] * mul : 0.f;
+            v[16 + r] = (pair && valid) ? y[pair ? t0 + 1 : t0][r] * mul : 0.f;
+        }
+        if (pair) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float keep = (l & 16) ? v[k + 16] : v[k], send = (l & 16) ? v[k] : v[k + 16];
+                v[k] = keep + __shfl_xor(send, 16);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] += __shfl_xor(v[k], 16);
+        }
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int k = 0; k < s; k++) {
+                const float keep = (l & s) ? v[k + s] : v[k], send = (l & s) ? v[k] : v[k + s];
+                v[k] = keep + __shfl_xor(send, s);
+            }
+        }
+        // lane l now holds value index l (pair) or l & 15 (single tile; both 16-lane groups hold the same totals)
+        const int idx = pair ? l : (l & 15);
+        const int d = 32 * (t0 + (idx >> 4)) + 8 * ((idx & 15) >> 2) + 4 * h + (idx & 3);
+        if ((pair || l < 16) && d < D) atomicAdd(bias_grad + d, v[0]);
+    }
+}
+
 // Causal work balance: query block i needs i+1 key tiles.  A workgroup takes the PAIR (nb-1-x, x) -- heavy one
 // first -- so every workgroup does nb+1 tiles (the middle block of an odd count runs alone).  grid.x = (nb+1)/2.
 __device__ __forceinline__ int pair_block(int ph, int nb, int x) {
@@ -486,7 +533,8 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                                          const T* __restrict__ d_o,
                                                                          const float* __restrict__ lse,
                                                                          float* __restrict__ delta, T* __restrict__ dqkv,
-                                                                         int Tn, int H, float scale, DropCfg drop) {
+                                                                         float* __restrict__ bias_grad, int Tn, int H, float scale,
+                                                                         DropCfg drop) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -601,6 +649,7 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
         }
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale * keep_scale, h);
+        if (bias_grad) colsum_t_tiles<T, D>(bias_grad + hd * D, qvalid, dq, scale * keep_scale, h, lane);
     }
 }
 
@@ -612,7 +661,8 @@ template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
                                                                           const float* __restrict__ lse,
                                                                           const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                                          int Tn, int H, float scale, DropCfg drop) {
+                                                                          float* __restrict__ bias_grad, int Tn, int H, float scale,
+                                                                          DropCfg drop) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -751,6 +801,10 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
             store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale * keep_scale, h);
             store_t_tile<T, D>(dvg, rs, key, kvalid, dt, dv[dt], keep_scale, h);
         }
+        if (bias_grad) {
+            colsum_t_tiles<T, D>(bias_grad + E + hd * D, kvalid, dk, scale * keep_scale, h, lane);
+            colsum_t_tiles<T, D>(bias_grad + 2 * E + hd * D, kvalid, dv, keep_scale, h, lane);
+        }
     }
 }
 
@@ -775,7 +829,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
 }
 template <typename T, int D>
 static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                      void* dqkv, int B, int Tn, int H, float scale, DropCfg d) {
+                      void* dqkv, int B, int Tn, int H, float scale, DropCfg d, float* bias_grad) {
     dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem + 1536 > 65536) {
@@ -786,13 +840,13 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
     }
     const double fl = (double)B * H * (double)Tn * Tn * D;        // one product over the unmasked half
     PROF_START(4, s);
-    if (d.thr) attn_dq_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
-    else attn_dq_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    if (d.thr) attn_dq_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+    else attn_dq_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
     PROF_STOP(4, s, 3.0 * fl);
     KERNEL_CHECK();
     PROF_START(5, s);
-    if (d.thr) attn_dkv_kernel<T, D, true><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
-    else attn_dkv_kernel<T, D, false><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, Tn, H, scale, d);
+    if (d.thr) attn_dkv_kernel<T, D, true><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+    else attn_dkv_kernel<T, D, false><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
     PROF_STOP(5, s, 4.0 * fl);
     KERNEL_CHECK();
     return CMP_OK;
@@ -818,6 +872,13 @@ extern "C" int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse
     else { DISPATCH_D(float, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
 }
 
+// One-shot: the next cmp_k_attn_bwd also adds the column sums of [dQ | dK | dV] to out[0..3E) (the c_attn bias gradient).
+static float* g_attn_bias_next = nullptr;
+extern "C" int cmp_attn_bwd_bias_next(float* out) {
+    g_attn_bias_next = out;
+    return CMP_OK;
+}
+
 extern "C" int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
                               float* delta_ws, void* dqkv, int B, int T, int H, int D, int scale, int dtype,
                               float p_drop, uint64_t seed, uint32_t rng_stream) {
@@ -825,6 +886,8 @@ extern "C" int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, cons
     hipStream_t s = (hipStream_t)stream;
     float sc = scale ? 1.0f / sqrtf((float)D) : 1.0f;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
-    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d) }
-    else { DISPATCH_D(float, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d) }
+    float* bias_grad = g_attn_bias_next;
+    g_attn_bias_next = nullptr;
+    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }
+    else { DISPATCH_D(float, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }
 }

@@ -518,11 +518,11 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         if (!ln) CHECK_RC(cmp_k_colsum(s, dao, E, m->G + o.proj_b, M, E, dt));
         CHECK_RC(gemm(m, 0, 1, M, E, E, dao, E, m->w(o.proj_w), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
                       0));                                                         // datt
+        CHECK_RC(cmp_attn_bwd_bias_next(m->G + o.attn_b));                         // b_attn grad = column sums of dqkv
         CHECK_RC(cmp_k_attn_bwd(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
                                 dt, pa, m->cfg.seed, drop_stream(step, i, 1)));
         CHECK_RC(gemm(m, 1, 0, E, 3 * E, M, a.u, E, m->dqkv, 3 * E, m->G + o.attn_w, 3 * E, nullptr, 0, nullptr, 0, nullptr, 0,
                       1, std::max(2, wgrad_splits(M, E, 3 * E)), 0.f, 0));
-        CHECK_RC(cmp_k_colsum(s, m->dqkv, 3 * E, m->G + o.attn_b, M, 3 * E, dt));
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
                           E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T

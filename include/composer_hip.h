@@ -181,6 +181,9 @@ int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int
 /* causal attention on qkv [B,T,3E] (head-merged, transformer.py:417): o [B,T,E], lse fp32 [B,H,T] */
 int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D,
                    int scale, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream);
+/* One-shot: the next cmp_k_attn_bwd also adds the column sums of [dQ | dK | dV] to out[0..3E): the c_attn bias gradient
+ * (Conv1D bias under tf.GradientTape, transformer.py:205-209, 916-920), taken from the f32 accumulators. */
+int cmp_attn_bwd_bias_next(float* out);
 int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
                    float* delta_ws, void* dqkv, int B, int T, int H, int D, int scale, int dtype,
                    float p_drop, uint64_t seed, uint32_t rng_stream);

@@ -320,10 +320,15 @@ def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
     oref.backward(do.double().cpu().reshape(B, T, E))
     dqkv = torch.zeros(B * T, 3 * E, device="cuda", dtype=tdt(dtype))
     delta = torch.zeros(B * H * T, device="cuda")
-    # backward consumes the kernel's own o / lse (as the train step does)
+    # backward consumes the kernel's own o / lse (as the train step does); armed: it also accumulates the c_attn bias
+    # gradient (column sums of [dQ|dK|dV]) from its f32 accumulators, on top of the vector's contents
+    bias_grad = torch.full((3 * E,), 2.0, device="cuda")
+    ck(lib, lib.cmp_attn_bwd_bias_next(P(bias_grad)))
     ck(lib, lib.cmp_k_attn_bwd(stream(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, dtype, p, 1234, 21))
     torch.cuda.synchronize()
     ref = x.grad.reshape(B * T, 3 * E)
+    assert rel_err(bias_grad, ref.sum(0) + 2.0) < tol
+    assert rel_err(delta, (do.double() * o.double()).reshape(B, T, H, D).sum(-1).permute(0, 2, 1).reshape(-1)) < tol
     for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
         assert rel_err(dqkv[:, sl], ref[:, sl]) < tol * 2, name
 
