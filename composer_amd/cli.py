@@ -4,8 +4,9 @@ Mirrors the commands, arguments and defaults of the reference's composer/cli.py 
 generate :617-680, make-config :69-78, summary :424-440) with the TensorFlow model replaced by the HIP one.  Out of
 scope: the MusicRNN model type, MIDI preprocessing/synthesis, TFRecord export.
 Documented divergences: `--temperature 0` means greedy argmax (the reference divides by the temperature, cli.py:671);
-prompts are given as event ids (`--prompt-ids` / `--prompt-data`) because MIDI parsing (pretty_midi) is outside the
-path; `--decode-mode` selects the literal loop of cli.py:663-676 or a real KV cache."""
+besides the reference's MIDI prompt (`--prompt`, read by composer_amd.midi instead of pretty_midi) a prompt can be given
+as event ids (`--prompt-ids` / `--prompt-data`), and an output path ending in `.data` gets event ids instead of a MIDI
+file; `--decode-mode` selects the literal loop of cli.py:663-676 or a real KV cache."""
 import datetime
 import logging
 import os
@@ -228,24 +229,27 @@ def evaluate(model_type, dataset_path, restoredir, use_generator, max_files):
 @click.argument('model-type', type=EnumType(ModelType, False))
 @click.argument('restoredir')
 @click.argument('output-filepath')
-@click.option('--prompt', '-p', 'prompt', default=None, help='MIDI prompt (needs the MIDI row, SURVEY 8f-3; not in this build).')
-@click.option('--prompt-ids', default=None, help='Comma-separated event ids to prompt the network with.')
-@click.option('--prompt-data', default=None, help='A .data file whose first events prompt the network.')
+@click.option('--prompt', '-p', 'prompt', default=None, help='The path of the MIDI file to prompt the network with.')
+@click.option('--prompt-ids', default=None, help='Comma-separated event ids to prompt the network with (instead of --prompt).')
+@click.option('--prompt-data', default=None, help='A .data file whose first events prompt the network (instead of --prompt).')
 @click.option('--prompt-length', default=10, help='Number of events to take from the start of the prompt. Defaults to 10.')
 @click.option('--length', '-l', 'generate_length', default=1024, help='The length of the generated event sequence. Defaults to 1024')
 @click.option('--temperature', default=1.0, help='Sampling temperature; 0 = greedy argmax. Defaults to 1.0.')
 @click.option('--decode-mode', type=click.Choice(['reference-literal', 'kv-cache']), default='kv-cache')
 def generate(model_type, restoredir, output_filepath, prompt, prompt_ids, prompt_data, prompt_length, generate_length,
              temperature, decode_mode):
-    """Generate an event sequence (cli.py:617-680); writes the generated ids as a `.data` file."""
+    """Generate a MIDI file (cli.py:617-680): MIDI prompt -> event ids -> model -> event ids -> MIDI.  An output path
+    ending in `.data` gets the event ids in the dataset's binary format instead of a MIDI file."""
+    from composer_amd import notes as nt
     config = get_config_from_restoredir(restoredir)
     model, _ = create_model(model_type, config, dtype='fp32')
     model.load_from_checkpoint(restoredir)
     model.compile(config.transformer.train.learning_rate)
     model.build(input_shape=(1, None))
-    if prompt is not None:
-        raise NotImplementedError('MIDI prompts need the MIDI reader (SURVEY 8f-3); use --prompt-ids or --prompt-data')
-    if prompt_ids is not None:
+    d = config.dataset
+    if prompt is not None:                                       # cli.py:645-660
+        x = nt.prompt_ids_from_midi(prompt, prompt_length, d.time_step_increment, d.max_time_steps, d.velocity_bins)
+    elif prompt_ids is not None:
         x = [int(t) for t in prompt_ids.split(',') if t.strip() != '']
     elif prompt_data is not None:
         x = ds.read_data_file(prompt_data)[0].astype(np.int32).tolist()
@@ -254,13 +258,16 @@ def generate(model_type, restoredir, output_filepath, prompt, prompt_ids, prompt
     x = x[:prompt_length]                                        # cli.py:649
     model.reset_states()
     ids = model.generate(x, generate_length, temperature=temperature, mode=decode_mode)
-    d = config.dataset
-    vr = ds.event_value_ranges(d.time_step_increment, d.max_time_steps, d.velocity_bins)
-    rg = ds.event_ranges(vr)
-    events = [ds.id_to_event(int(i), rg, vr) for i in list(x) + ids.tolist()]       # prompt + generated (cli.py:676)
+    all_ids = list(x) + ids.tolist()                             # prompt + generated (cli.py:676)
     out = Path(output_filepath)
     out.parent.mkdir(parents=True, exist_ok=True)
-    ds.write_data_file(out, events, d.time_step_increment, d.max_time_steps, d.velocity_bins)
+    if out.suffix == '.data':
+        vr = ds.event_value_ranges(d.time_step_increment, d.max_time_steps, d.velocity_bins)
+        rg = ds.event_ranges(vr)
+        events = [ds.id_to_event(int(i), rg, vr) for i in all_ids]
+        ds.write_data_file(out, events, d.time_step_increment, d.max_time_steps, d.velocity_bins)
+    else:                                                        # cli.py:678-680
+        nt.ids_to_midi(all_ids, out, d.time_step_increment, d.max_time_steps, d.velocity_bins)
     click.echo(','.join(str(int(i)) for i in ids))
 
 

@@ -71,3 +71,24 @@ def test_c1_train_evaluate_generate(tmp_path):
         assert agree >= 22, (mode, ids, want)
         got_ids, _ = D.read_data_file(tmp_path / "out.data")
         assert got_ids.tolist() == prompt + ids
+
+    # the reference's actual surface (cli.py:645-680): MIDI prompt in, MIDI file out
+    from composer_amd import notes as nt
+    vr = D.event_value_ranges(10, 100, 32)
+    rg = D.event_ranges(vr)
+    midi_prompt = tmp_path / "prompt.mid"
+    nt.NoteSequence([nt.Note(200.0 + 150 * i, 500.0 + 150 * i, 60 + (i % 12), 40 + 5 * i) for i in range(12)],
+                    [nt.SustainPeriod(300.0, 900.0)]).to_midi(midi_prompt)
+    want_prompt = nt.prompt_ids_from_midi(midi_prompt, 10)
+    res = r.invoke(cli.cli, ["generate", "transformer", str(run), str(tmp_path / "gen" / "song.mid"), "--prompt", str(midi_prompt),
+                             "--length", "64", "--temperature", "0"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    ids = [int(t) for t in res.output.strip().split("\n")[-1].split(",")]
+    assert len(ids) == 64
+    assert sum(a == b for a, b in zip(ids, orc.generate_kv(want_prompt, 64))) >= 60
+    # the MIDI file holds exactly the notes of (prompt + generated) events, to half a tick
+    events = [D.id_to_event(i, rg, vr) for i in want_prompt + ids]
+    direct = nt.NoteSequence.from_events(events)
+    reread = nt.NoteSequence.from_midi(tmp_path / "gen" / "song.mid", ignore_drums=False)
+    keep = [n for n in direct.notes if n.velocity > 0 and round(n.end * 0.44) > round(n.start * 0.44)]
+    assert sorted((n.pitch, n.velocity) for n in reread.notes) == sorted((n.pitch, n.velocity) for n in keep)

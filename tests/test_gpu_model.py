@@ -192,8 +192,9 @@ def test_single_rank_communicator_does_not_change_the_step():
 
 
 def test_deterministic_mode_is_bitwise_reproducible(monkeypatch):
-    """COMPOSER_DETERMINISTIC=1: split-K wgrads reduce per-split slabs in a fixed order.  (Embedding scatter-add and
-    LayerNorm parameter partials still use float atomics with <= 32 addends per address.)"""
+    """COMPOSER_DETERMINISTIC=1: split-K wgrads (every Conv1D weight gradient) reduce per-split slabs in a fixed order.
+    (The embedding scatter-add, the LayerNorm parameter partials and the bias gradients -- column sums accumulated by the
+    GEMM / attention-backward epilogues -- still use float atomics; they are not part of this guarantee.)"""
     monkeypatch.setenv("COMPOSER_DETERMINISTIC", "1")
     g, cfg, params = load_golden("gB")
     from composer_amd import _lib
