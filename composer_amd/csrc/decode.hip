@@ -113,7 +113,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // in flight at once (K <= 64*4*GV_MAXI).  IN: 0 plain copy, 1 LayerNorm (every workgroup recomputes the row statistics of
 // the 2-8 KiB input: cheaper than another launch), 2 combine of the split-key attention partials.
 #define GV_MAXI 12
-#define ATT_SPLITS 4
+#define ATT_SPLITS 8        // 4: 206 us/token, 8: 194, 16: 222 (the combine in the next GEMV grows), same-box
 template <int ACT, int IN>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, float eps,
@@ -123,6 +123,16 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [K] + 8
     float* red = xs + K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this wave's weight row is requested FIRST: it does not depend on the input, and the LayerNorm / combine prologue
+    // below (two block reductions) then runs under the HBM/L2 latency instead of in front of it
+    const int n = blockIdx.x * 4 + wave;
+    const float* wr = Wt + (int64_t)min(n, N - 1) * K;
+    f32x4 wv[GV_MAXI];
+#pragma unroll
+    for (int i = 0; i < GV_MAXI; i++) {
+        const int k = (lane + 64 * i) * 4;
+        wv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(wr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     if (IN == 1) {
         float s = 0.f;
         for (int k = tid; k < K; k += 256) s += x[k];
@@ -137,21 +147,29 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
             if (u_out && blockIdx.x == 0) u_out[k] = v;
         }
     } else if (IN == 2) {
-        // x: attention partials [H][ATT_SPLITS][D+2] = {o[D] (unnormalised), running max, sum}; K = H*D
-        for (int k = tid; k < K; k += 256) {
-            const int h = k / D, dd = k % D;
+        // x: attention partials [H][ATT_SPLITS][D+2] = {o[D] (unnormalised), running max, sum}; K = H*D.
+        // First the H*ATT_SPLITS combine weights exp(m_s - m) / sum (one exponential each), then the weighted sums.
+        float* cw = red + 8;                              // [H * ATT_SPLITS] (the launcher sizes the LDS for it)
+        const int H = K / D;
+        for (int t = tid; t < H * ATT_SPLITS; t += 256) {
+            const int h = t / ATT_SPLITS;
             const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
             float mx = -INFINITY;
 #pragma unroll
             for (int s = 0; s < ATT_SPLITS; s++) mx = fmaxf(mx, p[s * (D + 2) + D]);
-            float num = 0.f, den = 0.f;
+            float den = 0.f;
 #pragma unroll
-            for (int s = 0; s < ATT_SPLITS; s++) {
-                const float w = expf(p[s * (D + 2) + D] - mx);       // exp(-inf) = 0 for empty splits
-                num += w * p[s * (D + 2) + dd];
-                den += w * p[s * (D + 2) + D + 1];
-            }
-            xs[k] = num / den;
+            for (int s = 0; s < ATT_SPLITS; s++) den += expf(p[s * (D + 2) + D] - mx) * p[s * (D + 2) + D + 1];
+            cw[t] = expf(p[(t % ATT_SPLITS) * (D + 2) + D] - mx) / den;      // exp(-inf) = 0 for empty splits
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += 256) {
+            const int h = k / D, dd = k % D;
+            const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
+            float num = 0.f;
+#pragma unroll
+            for (int s = 0; s < ATT_SPLITS; s++) num += cw[h * ATT_SPLITS + s] * p[s * (D + 2) + dd];
+            xs[k] = num;
         }
     } else {
         for (int k = tid; k < K; k += 256) {
@@ -161,15 +179,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    const int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
-    const float* wr = Wt + (int64_t)n * K;
-    f32x4 wv[GV_MAXI];
-#pragma unroll
-    for (int i = 0; i < GV_MAXI; i++) {
-        const int k = (lane + 64 * i) * 4;
-        wv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(wr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < GV_MAXI; i++) {
@@ -341,7 +351,7 @@ static int launch_gemv(hipStream_t s, int act, int in_mode, const float* x, cons
                        const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D) {
     CMP_REQUIRE(K % 4 == 0 && K <= 256 * GV_MAXI, "decode gemv: K=%d unsupported (max %d)", K, 256 * GV_MAXI);
     int grid = cdiv(N, 4);
-    size_t smem = (size_t)(K + 8) * 4;
+    size_t smem = (size_t)(K + 8 + (in_mode == 2 ? (K / D) * ATT_SPLITS : 0)) * 4;      // input | reduction scratch | combine weights
 #define GV(A, I) dec_gemv_kernel<A, I><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D)
     if (act == 1) { if (in_mode == 1) GV(1, 1); else if (in_mode == 2) GV(1, 2); else GV(1, 0); }
     else { if (in_mode == 1) GV(0, 1); else if (in_mode == 2) GV(0, 2); else GV(0, 0); }
