@@ -626,16 +626,20 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                         s[r] = p * (dp[r] - del_q);
                     }
                 } else {
+                    // the mask is applied in its own loop under ONE wave-uniform branch: inside the element loop hipcc
+                    // emitted a scalar branch per element (15 s_cbranch per sub-tile in the ISA)
                     const bool edge = (k0 + 31 > q0w) || (k0 + 32 > Tn) || (q0w + 32 > Tn);
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        float p = fast_exp2(fmaf(s[r], c2, -lse2));
-                        if (edge) {
-                            int key = k0 + rho(r, h);
-                            if ((key > q) || (key >= Tn) || !qvalid) p = 0.f;
+                    for (int r = 0; r < 16; r++) s[r] = fast_exp2(fmaf(s[r], c2, -lse2));
+                    if (edge) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int key = k0 + rho(r, h);
+                            if ((key > q) || (key >= Tn) || !qvalid) s[r] = 0.f;
                         }
-                        s[r] = p * (dp[r] - del_q);
                     }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) s[r] *= dp[r] - del_q;
                 }
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) dq[dt] = mma_acc_b<T, D>(Ks, 32 * sub, dt, s, lane, dq[dt]);
@@ -765,13 +769,19 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
                 f32x16 pt;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    float p;
-                    if constexpr (EXACT) p = expf(s[r] * scale - lq[r >> 2][r & 3]);
-                    else p = fast_exp2(fmaf(s[r], c2, -lq[r >> 2][r & 3]));        // lse*log2(e) in this mode
-                    if (edge) {
+                    if constexpr (EXACT) pt[r] = expf(s[r] * scale - lq[r >> 2][r & 3]);
+                    else pt[r] = fast_exp2(fmaf(s[r], c2, -lq[r >> 2][r & 3]));        // lse*log2(e) in this mode
+                }
+                if (edge) {          // one wave-uniform branch around the whole mask loop (see the dQ kernel)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
                         const int qq = qt0 + 32 * sub + rho(r, h);
-                        if ((key > qq) || (qq >= Tn) || !kvalid) p = 0.f;
+                        if ((key > qq) || (qq >= Tn) || !kvalid) pt[r] = 0.f;
                     }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float p = pt[r];
                     float dpv = dp[r];
                     float pd = p;
                     if constexpr (DROP) {
