@@ -54,6 +54,22 @@ def pmc_traffic(kernel_class, batch):
     return doc.get("class0_forward_gemm_mean_bytes_per_launch")
 
 
+class stdout_to_stderr:
+    """gloo and RCCL print connection / version banners on fd 1 while they initialise; the contract is ONE JSON line on
+    stdout, so fd 1 points at stderr for the duration."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def flops_per_token_train():
     fwd = L * (24 * E * E + 2 * E * T) + 2 * E * V          # causal attention counted on the unmasked half
     return 3 * fwd
@@ -132,7 +148,8 @@ def main():
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)     # bootstrap + timing only; gradients go over RCCL
+        with stdout_to_stderr():
+            dist.init_process_group("gloo", rank=rank, world_size=world)     # bootstrap + timing only; gradients go over RCCL
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -141,9 +158,11 @@ def main():
                         dtype="bf16", seed=1000 + rank, max_batch=Bq, max_seq=T, device=local_rank)
     model.initialize_parameters(0)                  # identical replicas
     if world > 1 or under_launcher:      # a 1-rank launch exercises the same RCCL path (buckets, side stream, 1/N scale)
-        uid = [Transformer.new_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        model.init_data_parallel(rank, world, uid[0])
+        with stdout_to_stderr():
+            uid = [Transformer.new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            model.init_data_parallel(rank, world, uid[0])
+            model.synchronize()
 
     # synthetic inputs, resident in HBM before the timed region
     n_data = 4

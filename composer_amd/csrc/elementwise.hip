@@ -149,20 +149,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             gm[i][j] = (c < chunks) ? gamma[c * VN + j] : 0.f;
         }
     }
-    for (int row = blockIdx.x * wpb + wave; row < rows; row += gridDim.x * wpb) {
-        const float mu = mean[row], rs = rstd[row];
-        Vec16<T> vdy[MAXI], vx[MAXI];
+    // Software pipeline over the rows of this wave: the three input rows (dy, x, residual) and the statistics of the NEXT
+    // row are requested before the current row is reduced and written, so ~6 KiB per wave (~96 KiB per CU at 4 waves
+    // per SIMD) stay in flight.  (Before: dy/x, two wave reductions, THEN the residual row -- two exposed HBM latencies
+    // per row and 3 KiB per wave in flight: 4.7 TB/s.)
+    struct RowIn {
+        Vec16<T> dy[MAXI], x[MAXI], r[MAXI];
+        float mu, rs;
+    };
+    auto fetch = [&](int row, RowIn& in) {
+        in.mu = mean[row];
+        in.rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < MAXI; i++) {
+            const int c = lane + 64 * i;
+            if (c < chunks) {
+                in.dy[i] = ld16(dy + (int64_t)row * E + c * VN);
+                in.x[i] = ld16(x + (int64_t)row * E + c * VN);
+                if (resid) in.r[i] = ld16(resid + (int64_t)row * E + c * VN);
+            }
+        }
+    };
+    const int stride = gridDim.x * wpb;
+    int row = blockIdx.x * wpb + wave;
+    RowIn cur, nxt;
+    if (row < rows) fetch(row, cur);
+    for (; row < rows; row += stride) {
+        const bool more = row + stride < rows;
+        if (more) fetch(row + stride, nxt);
+        const float mu = cur.mu, rs = cur.rs;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
-                vdy[i] = ld16(dy + (int64_t)row * E + c * VN);
-                vx[i] = ld16(x + (int64_t)row * E + c * VN);
 #pragma unroll
                 for (int j = 0; j < VN; j++) {
-                    float d = vdy[i].get(j);
-                    float xh = (vx[i].get(j) - mu) * rs;
+                    float d = cur.dy[i].get(j);
+                    float xh = (cur.x[i].get(j) - mu) * rs;
                     float g = d * gm[i][j];
                     s1 += g;
                     s2 += g * xh;
@@ -178,14 +202,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
-                Vec16<T> o, r, om;
-                if (resid) r = ld16(resid + (int64_t)row * E + c * VN);
+                Vec16<T> o, om;
 #pragma unroll
                 for (int j = 0; j < VN; j++) {
-                    float xh = (vx[i].get(j) - mu) * rs;
-                    float g = vdy[i].get(j) * gm[i][j];
+                    float xh = (cur.x[i].get(j) - mu) * rs;
+                    float g = cur.dy[i].get(j) * gm[i][j];
                     float v = rs * (g - s1 - xh * s2);
-                    if (resid) v += r.get(j);
+                    if (resid) v += cur.r[i].get(j);
                     o.set(j, v);
                     if (want_colsum) {
                         // the consumer sees the STORED (rounded) value
@@ -198,6 +221,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 if (dmask) st16(dmask + (int64_t)row * E + c * VN, om);
             }
         }
+        if (more) cur = nxt;
     }
     // cross-wave reduction of the parameter-gradient partials
     float* sm = ln_smem + (size_t)wave * 3 * E;
