@@ -30,8 +30,8 @@ LR = 1e-3
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 KERNEL_CLASSES = {
-    0: ("gemm_bf16_p4_kernel<A[M,K],B[K,N]> (forward Conv1D: c_attn/c_proj/c_fc/mlp c_proj, tied logits)", "mfma"),
-    1: ("gemm_bf16_256_kernel<B stored [N,K]> (dgrad)", "mfma"),
+    0: ("gemm_bf16_256_kernel<A[M,K], W^T[N,K]> (forward Conv1D: c_attn/c_proj/c_fc/mlp c_proj, tied logits)", "mfma"),
+    1: ("gemm_bf16_256_kernel<A[M,N], W[K,N]> (dgrad)", "mfma"),
     2: ("gemm_bf16_p4_kernel<A stored [K,M]> (wgrad, split-K f32 atomics)", "mfma"),
     3: ("attn_fwd_kernel<bf16,64>", "mfma"),
     4: ("attn_dq_kernel<bf16,64>", "mfma"),

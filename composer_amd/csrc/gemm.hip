@@ -1340,6 +1340,11 @@ __global__ void gemm_slab_reduce_kernel(const float* __restrict__ slab, float* _
 // One-shot: the NEXT cmp_k_gemm also adds the column sums of its output to out[0..N) (bias gradient of the layer that
 // produced the GEMM's input gradient).  Fused into the epilogue where a compile-time kind runs (saves re-reading the
 // output: 84 us per layer for the [M,4E] MLP gradient at B=128), otherwise a cmp_k_colsum pass after the launch.
+static int g_gemm_role = -1;
+int gemm_set_role(int role) {       // internal (model.hip): profiler class of the following cmp_k_gemm calls; -1 = by layout
+    g_gemm_role = role;
+    return CMP_OK;
+}
 static float* g_colsum_next = nullptr;
 extern "C" int cmp_gemm_colsum_next(float* out) {
     g_colsum_next = out;
@@ -1372,6 +1377,7 @@ static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, 
         if (kind == EPI_PLAIN) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_PLAIN>); return true; }
         if (kind == EPI_RESID) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_RESID>); return true; }
         if (kind == EPI_GELUGRAD) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_GELUGRAD>); return true; }
+        if (kind == EPI_GELU_AUX) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_GELU_AUX>); return true; }
     }
     if (swap)
         gemm_bf16_256_kernel<A_KM, B_KM, true><<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
@@ -1438,7 +1444,9 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
         size_t smem = 4 * G_IMG;
         const bf16_t* a = (const bf16_t*)A;
         const bf16_t* b = (const bf16_t*)Bm;
-        const int cls = ta ? 2 : (tb ? 1 : 0);
+        // timing class of cmp_prof_*: by role when the caller announced one (the model: 0 forward, 1 dgrad, 2 wgrad),
+        // otherwise by layout (the forward GEMMs read a transposed weight copy, i.e. the dgrad layout)
+        const int cls = g_gemm_role >= 0 ? g_gemm_role : (ta ? 2 : (tb ? 1 : 0));
         // fast path: direct-to-LDS staging needs every 64-deep k-step of a K-contiguous operand inside its row
         // (K % 64 == 0, or the caller vouches for zero padding up to a multiple of 64 with CMP_GEMM_KPAD_ZERO) and
         // 32-bit byte offsets.

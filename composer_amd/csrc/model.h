@@ -51,6 +51,11 @@ struct LayerOff {   // element offsets into the flat buffers
     int64_t begin, end;
 };
 
+struct WDesc {      // one Conv1D weight in the flat buffers: [rows = in][cols = out]
+    int64_t off;
+    int rows, cols;
+};
+
 struct LayerAct {
     void *u, *qkv, *att, *r, *n, *fc, *g;
     float *ln1_mean, *ln1_rstd, *ln2_mean, *ln2_rstd, *lse;
@@ -69,6 +74,12 @@ struct cmp_model {
     std::vector<LayerOff> lo;
     float *P = nullptr, *G = nullptr, *Am = nullptr, *Av = nullptr;
     bf16_t* S = nullptr;       // bf16 shadow (bf16 mode)
+    // Transposed bf16 copies of the four Conv1D weights of every block ([in,out] -> [out,in], same flat offsets), refreshed
+    // at the top of every forward pass: with the weight K-contiguous the forward GEMMs run on the kernel whose both
+    // operands are read with ds_read_b128 (c_attn 275 -> 209 us, c_fc 393 -> 350, c_proj 104 -> 93, mlp c_proj 298 -> 272
+    // at B=128); the refresh moves 38 MB (~12 us).
+    bf16_t* ST = nullptr;
+    void* wdesc = nullptr;     // device table of (offset, rows, cols) for the 4L matrices
     int64_t iterations = 0;
     // workspace
     int capB = 0, capT = 0;
@@ -88,6 +99,7 @@ struct cmp_model {
     std::vector<hipEvent_t> bucket_ev; // L+2 events
     hipEvent_t comm_done = nullptr;
     DecodeState* dec = nullptr;
+    int gemm_role = -1;                // profiler class announced to cmp_k_gemm (0 while the forward pass is enqueued)
 
     const void* w(int64_t off) const { return dtype == CMP_BF16 ? (const void*)(S + off) : (const void*)(P + off); }
 };
@@ -104,6 +116,7 @@ template <typename Tp> static int dev_alloc(cmp_model* m, Tp** p, size_t bytes) 
 // elementwise.hip
 int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics);
 int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n);
+int gemm_set_role(int role);      // gemm.hip: profiler class override (0 forward, 1 dgrad, 2 wgrad, -1 by layout)
 // model.hip
 int ensure_workspace(cmp_model* m, int B, int T);
 int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step);

@@ -213,6 +213,18 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     if (m->dtype == CMP_BF16) {
         CHECK_RC(dev_alloc(m, &m->S, (size_t)m->total * 2));
         HIP_CHECK(hipMemsetAsync(m->S, 0, (size_t)m->total * 2, ctx->stream));
+        CHECK_RC(dev_alloc(m, &m->ST, (size_t)m->total * 2));
+        HIP_CHECK(hipMemsetAsync(m->ST, 0, (size_t)m->total * 2, ctx->stream));
+        std::vector<WDesc> wd;
+        for (int i = 0; i < m->L; i++) {
+            const LayerOff& o = m->lo[i];
+            wd.push_back({o.attn_w, m->E, 3 * m->E});
+            wd.push_back({o.proj_w, m->E, m->E});
+            wd.push_back({o.fc_w, m->E, 4 * m->E});
+            wd.push_back({o.pr_w, 4 * m->E, m->E});
+        }
+        CHECK_RC(dev_alloc(m, &m->wdesc, wd.size() * sizeof(WDesc)));
+        HIP_CHECK(hipMemcpy(m->wdesc, wd.data(), wd.size() * sizeof(WDesc), hipMemcpyHostToDevice));
     }
     CHECK_RC(dev_alloc(m, &m->metrics, sizeof(Metrics)));
     CHECK_RC(dev_alloc(m, &m->dp_metrics, 16));
@@ -384,6 +396,31 @@ static int drop_apply(cmp_model* m, const void* in, void* out, int64_t n, float 
     return CMP_OK;
 }
 
+// transposed weight shadow: 32x32 tiles through LDS, grid (tiles of the largest matrix, 4L matrices)
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const bf16_t* __restrict__ S, bf16_t* __restrict__ ST,
+                                                                const WDesc* __restrict__ desc) {
+    __shared__ bf16_t tile[32][34];
+    const WDesc d = desc[blockIdx.y];
+    const int tiles_c = d.cols >> 5, ntiles = (d.rows >> 5) * tiles_c;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int tr = (blockIdx.x / tiles_c) << 5, tc = (blockIdx.x % tiles_c) << 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const bf16_t* src = S + d.off;
+    bf16_t* dst = ST + d.off;
+#pragma unroll
+    for (int j = 0; j < 4; j++) tile[ty + 8 * j][tx] = src[(int64_t)(tr + ty + 8 * j) * d.cols + tc + tx];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) dst[(int64_t)(tc + ty + 8 * j) * d.rows + tr + tx] = tile[tx][ty + 8 * j];
+}
+static int refresh_transposed_weights(cmp_model* m) {
+    if (!m->ST) return CMP_OK;
+    const int maxtiles = (4 * m->E / 32) * (m->E / 32);
+    transpose_weights_kernel<<<dim3(maxtiles, 4 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 // forward: Transformer.call (transformer.py:696-833) with past=None
 // -------------------------------------------------------------------------------------------------
@@ -392,38 +429,49 @@ static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A
                 int splitk, float p_drop, uint32_t rng_stream, int flags = 0) {
     const bool use_slab = splitk > 1 && m->slab != nullptr;
     if (use_slab) cmp_gemm_set_workspace(m->slab, m->slab_bytes);     // registered only around this launch
+    gemm_set_role(m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1));   // forward announces 0; backward: A^T = wgrad, else dgrad
     int rc = cmp_k_gemm(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
                         out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags);
     if (use_slab) cmp_gemm_set_workspace(nullptr, 0);
+    gemm_set_role(-1);
     return rc;
 }
 
 int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step) {
     hipStream_t s = m->ctx->stream;
+    struct RoleGuard {
+        cmp_model* m;
+        RoleGuard(cmp_model* mm) : m(mm) { m->gemm_role = 0; }
+        ~RoleGuard() { m->gemm_role = -1; }
+    } role_guard(m);
     const int E = m->E, M = B * T, dt = m->dtype;
     const float pr = training ? m->cfg.resid_dropout : 0.f;
     const float pa = training ? m->cfg.attn_dropout : 0.f;
     const bool ln = m->cfg.use_layer_norm != 0;
     CHECK_RC(cmp_k_embed_fwd(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, 0, dt, pr, m->cfg.seed,
                              drop_stream(step, 0, 0)));
+    CHECK_RC(refresh_transposed_weights(m));
+    // Conv1D weight operand of the forward GEMMs: [in,out] as stored (fp32 mode), or the transposed bf16 copy (tb = 1)
+    const bool wt = m->ST != nullptr;
+    auto W = [&](int64_t off) { return wt ? (const void*)(m->ST + off) : m->w(off); };
     for (int i = 0; i < m->L; i++) {
         const LayerOff& o = m->lo[i];
         LayerAct& a = m->act[i];
         if (ln)   // transformer.py:583-584 -- the LN output REPLACES the residual stream
             CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[i], m->P + o.ln1_g, m->P + o.ln1_b, a.u, a.ln1_mean, a.ln1_rstd, M, E,
                                          m->cfg.ln_eps, dt));
-        CHECK_RC(gemm(m, 0, 0, M, 3 * E, E, a.u, E, m->w(o.attn_w), 3 * E, a.qkv, 3 * E, m->P + o.attn_b, 0, nullptr, 0,
+        CHECK_RC(gemm(m, 0, wt, M, 3 * E, E, a.u, E, W(o.attn_w), wt ? E : 3 * E, a.qkv, 3 * E, m->P + o.attn_b, 0, nullptr, 0,
                       nullptr, 0, 0, 1, 0.f, 0));
         CHECK_RC(cmp_k_attn_fwd(s, a.qkv, a.att, a.lse, B, T, m->H, m->D, m->cfg.scale_attention, dt, pa, m->cfg.seed,
                                 drop_stream(step, i, 1)));
-        CHECK_RC(gemm(m, 0, 0, M, E, E, a.att, E, m->w(o.proj_w), E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
+        CHECK_RC(gemm(m, 0, wt, M, E, E, a.att, E, W(o.proj_w), E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
                       drop_stream(step, i, 2)));                                   // r = u + dropout(proj)  :587
         if (ln)
             CHECK_RC(cmp_k_layernorm_fwd(s, a.r, m->P + o.ln2_g, m->P + o.ln2_b, a.n, a.ln2_mean, a.ln2_rstd, M, E,
                                          m->cfg.ln_eps, dt));
-        CHECK_RC(gemm(m, 0, 0, M, 4 * E, E, a.n, E, m->w(o.fc_w), 4 * E, a.g, 4 * E, m->P + o.fc_b, 1, a.fc, 4 * E, nullptr, 0,
+        CHECK_RC(gemm(m, 0, wt, M, 4 * E, E, a.n, E, W(o.fc_w), wt ? E : 4 * E, a.g, 4 * E, m->P + o.fc_b, 1, a.fc, 4 * E, nullptr, 0,
                       0, 1, 0.f, 0));                                              // g = gelu(fc)           :504
-        CHECK_RC(gemm(m, 0, 0, M, E, 4 * E, a.g, 4 * E, m->w(o.pr_w), E, m->xs[i + 1], E, m->P + o.pr_b, 0, nullptr, 0, a.r, E,
+        CHECK_RC(gemm(m, 0, wt, M, E, 4 * E, a.g, 4 * E, W(o.pr_w), wt ? 4 * E : E, m->xs[i + 1], E, m->P + o.pr_b, 0, nullptr, 0, a.r, E,
                       0, 1, pr, drop_stream(step, i, 3)));                         // x = r + dropout(mlp)   :594
     }
     CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[m->L], m->P + m->off_lnf_g, m->P + m->off_lnf_b, m->hf, m->lnf_mean, m->lnf_rstd, M,

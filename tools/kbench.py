@@ -58,15 +58,29 @@ def gemm_case(name, ta, tb, m, n, k, splitk=1, out_fp32=False, bias=False, act=0
     return us
 
 
+def bench_gemm_fwd():
+    """only the four forward GEMMs of a layer (the PMC traffic pass of tools/profile_round.sh)"""
+    gemm_case("fwd c_attn (+bias)", 0, 1, M, 3 * E, E, bias=True)
+    gemm_case("fwd attn c_proj (+bias,+resid)", 0, 1, M, E, E, bias=True, resid=True)
+    gemm_case("fwd c_fc (+bias,gelu,aux)", 0, 1, M, 4 * E, E, bias=True, act=1)
+    gemm_case("fwd mlp c_proj (+bias,+resid)", 0, 1, M, E, 4 * E, bias=True, resid=True)
+
+
 def bench_gemm():
     tot = 0
     if os.environ.get("KBENCH_SLABS"):
         ws = torch.empty(64 * E * E + 64, device="cuda")
         lib.cmp_gemm_set_workspace(P(ws), ws.numel() * 4)
-    tot += gemm_case("fwd c_attn (+bias)", 0, 0, M, 3 * E, E, bias=True)
-    tot += gemm_case("fwd attn c_proj (+bias,+resid)", 0, 0, M, E, E, bias=True, resid=True)
-    tot += gemm_case("fwd c_fc (+bias,gelu,aux)", 0, 0, M, 4 * E, E, bias=True, act=1)
-    tot += gemm_case("fwd mlp c_proj (+bias,+resid)", 0, 0, M, E, 4 * E, bias=True, resid=True)
+    # forward: the model feeds the transposed bf16 weight copy (tb = 1: both operands K-contiguous)
+    tot += gemm_case("fwd c_attn (+bias)", 0, 1, M, 3 * E, E, bias=True)
+    tot += gemm_case("fwd attn c_proj (+bias,+resid)", 0, 1, M, E, E, bias=True, resid=True)
+    tot += gemm_case("fwd c_fc (+bias,gelu,aux)", 0, 1, M, 4 * E, E, bias=True, act=1)
+    tot += gemm_case("fwd mlp c_proj (+bias,+resid)", 0, 1, M, E, 4 * E, bias=True, resid=True)
+    if os.environ.get("KBENCH_BN"):      # the same with the weight as stored, [K,N] (deep-pipeline kernel)
+        gemm_case("fwd c_attn, W[K,N]", 0, 0, M, 3 * E, E, bias=True)
+        gemm_case("fwd attn c_proj, W[K,N]", 0, 0, M, E, E, bias=True, resid=True)
+        gemm_case("fwd c_fc, W[K,N]", 0, 0, M, 4 * E, E, bias=True, act=1)
+        gemm_case("fwd mlp c_proj, W[K,N]", 0, 0, M, E, 4 * E, bias=True, resid=True)
     tot += gemm_case("dgrad mlp c_proj (*gelu')", 0, 1, M, 4 * E, E, act=2)
     tot += gemm_case("dgrad c_fc", 0, 1, M, E, 4 * E)
     tot += gemm_case("dgrad attn c_proj", 0, 1, M, E, E)
@@ -127,6 +141,8 @@ if __name__ == "__main__":
     torch.zeros(1, device="cuda")
     if "gemm" in what:
         bench_gemm()
+    if "gemmfwd" in what:
+        bench_gemm_fwd()
     if "attn" in what:
         bench_attn()
     if "ln" in what:

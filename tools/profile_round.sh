@@ -13,7 +13,7 @@ timeout 600 python bench.py > $out/bench_c2.json 2> $out/bench_c2.err; cut -c1-2
 timeout 600 python bench.py --batch 32 --no-cpu-baseline --no-decode > $out/bench_c2_b32.json 2>> $out/bench_c2.err; cut -c1-200 $out/bench_c2_b32.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 bench.py --no-cpu-baseline --no-decode --steps 10 --warmup 3 > $out/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  KB_B=128 timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o k -- python3 tools/kbench.py gemm > $out/pmc_$c.log 2>&1
+  KB_B=128 timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o k -- python3 tools/kbench.py gemmfwd > $out/pmc_$c.log 2>&1
   python3 tools/pmc_summary.py $out/pmc_$c gemm > $out/pmc_${c}_summary.txt
 done
 KB_B=128 timeout 200 python tools/kbench.py gemm > $out/kbench_gemm.txt 2>&1
