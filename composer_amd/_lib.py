@@ -58,6 +58,7 @@ SIGNATURES = {
     "cmp_train_metrics": (_i, [_P, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_loss_and_grads": (_i, [_P, _P, _P, _i, _i, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_eval_step": (_i, [_P, _P, _P, _i, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
+    "cmp_present_get": (_i, [_P, _i, _i, _i, _P]),
     "cmp_forward_logits": (_i, [_P, _P, _i, _i, _P]),
     "cmp_decode_begin": (_i, [_P, _P, _i, _i, _f, _u64]),
     "cmp_decode_steps": (_i, [_P, _i, _P]),

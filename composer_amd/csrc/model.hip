@@ -677,6 +677,39 @@ extern "C" int cmp_eval_step(cmp_model* m, const int32_t* x, const int32_t* y, i
     return CMP_OK;
 }
 
+// presents[layer] = stack([key, value]) with key, value [B,H,T,D] (split_heads of the c_attn output; transformer.py:417-435,
+// 797-806): gathered from the qkv activation [B*T, 3E] the last forward pass saved
+template <typename T_>
+__global__ void present_gather_kernel(const T_* __restrict__ qkv, float* __restrict__ out, int B, int T, int H, int D) {
+    const int E = H * D;
+    const int64_t n = (int64_t)2 * B * H * T * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int t = (int)((i / D) % T);
+        const int h = (int)((i / ((int64_t)D * T)) % H);
+        const int b = (int)((i / ((int64_t)D * T * H)) % B);
+        const int kv = (int)(i / ((int64_t)D * T * H * B));
+        out[i] = to_f32<T_>(qkv[((int64_t)b * T + t) * 3 * E + (1 + kv) * E + h * D + d]);
+    }
+}
+extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out) {
+    CMP_REQUIRE(m && host_out, "present_get: null argument");
+    CMP_REQUIRE(layer >= 0 && layer < m->L, "present_get: layer %d outside [0, %d)", layer, m->L);
+    CMP_REQUIRE(B > 0 && T > 0 && (int64_t)B * T <= (int64_t)m->capB * m->capT && !m->act.empty(), "present_get: no forward pass of shape [%d,%d] is held", B, T);
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    const int64_t n = (int64_t)2 * B * m->H * T * m->D;
+    float* tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
+    const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
+    if (m->dtype == CMP_BF16) present_gather_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)m->act[layer].qkv, tmp, B, T, m->H, m->D);
+    else present_gather_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)m->act[layer].qkv, tmp, B, T, m->H, m->D);
+    hipError_t e = hipMemcpyAsync(host_out, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, m->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(tmp);
+    HIP_CHECK(e);
+    return CMP_OK;
+}
+
 extern "C" int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logits_out) {
     CMP_REQUIRE(m && x && logits_out, "forward_logits: null argument");
     HIP_CHECK(hipSetDevice(m->ctx->device));

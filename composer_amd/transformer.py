@@ -241,7 +241,12 @@ class Transformer:
         return (logits,)
 
     def _fetch_present(self, layer, B, T):
-        raise NotImplementedError('presents are kept on the device (KV cache); not exported in this build')
+        """presents[layer] = stack([key, value]) [2,B,H,T,D] of the forward pass that produced this Presents object
+        (valid until the next forward / train step of the model)."""
+        H = self.attention_head_count
+        out = np.empty((2, B, H, T, self.embedding_size // H), np.float32)
+        _lib.check(self._lib.cmp_present_get(self._h, int(layer), B, T, out.ctypes.data_as(C.c_void_p)), 'cmp_present_get')
+        return out
 
     def train_step(self, x, y, learning_rate=None, sync=True):
         """One iteration of transformer.py:914-930: returns (loss, accuracy) of this rank's batch."""

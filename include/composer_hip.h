@@ -115,6 +115,9 @@ int cmp_eval_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T
 /* ---- inference forward: Transformer.call(inputs, training=False) (transformer.py:696-833) -------
  * logits_out: host fp32 [B,T,V]. */
 int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logits_out);
+/* presents[layer] of the LAST forward pass (Transformer.call's second result, transformer.py:797-806, 820-821):
+ * host fp32 [2, B, H, T, D] = stack([key, value]) after split_heads.  B, T must be that pass's shape. */
+int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out);
 
 /* ---- decode: the loop of cli.py:659-676 -------------------------------------------------------
  * temperature <= 0 => argmax with lowest-index tie-break (the tau->0 limit; cli.py:671 divides). */

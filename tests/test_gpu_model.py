@@ -191,6 +191,26 @@ def test_single_rank_communicator_does_not_change_the_step():
     m.close()
 
 
+def test_presents_match_the_oracle():
+    """Transformer.call returns (logits, presents) (transformer.py:797-806, 820-821): presents[l] = stack([key, value]) of
+    layer l, [2,B,H,T,D], exported from the device through cmp_present_get."""
+    g, cfg, params = load_golden("gA")
+    V, E, H, L, W, T, B = cfg
+    m = make_model(cfg, params, "fp32")
+    x = g["x"][0]
+    logits, presents = m(x)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), {k: v.astype(np.float64) for k, v in params.items()})
+    ologits, opresents, _ = orc.forward(x)
+    assert np.abs(logits - ologits).max() <= 1e-4
+    assert len(presents) == L
+    for l, p in enumerate(presents):
+        assert p.shape == (2, B, H, T, E // H)
+        assert np.abs(p - opresents[l]).max() <= 2e-5 * max(1.0, np.abs(opresents[l]).max()), l
+    with pytest.raises(IndexError):
+        presents[L]
+    m.close()
+
+
 def test_deterministic_mode_is_bitwise_reproducible(monkeypatch):
     """COMPOSER_DETERMINISTIC=1: split-K wgrads (every Conv1D weight gradient) reduce per-split slabs in a fixed order.
     (The embedding scatter-add, the LayerNorm parameter partials and the bias gradients -- column sums accumulated by the
