@@ -23,6 +23,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL / cross-process GPU memory sharing on this pool needs dmabuf IPC (the image exports it; keep it if a launcher dropped it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 V, E, H, L, W, T = 390, 512, 8, 6, 1024, 1024
 B_PER_GPU = 128       # per-GPU batch: not fixed by BASELINE; sweep in DESIGN.md section 7 (B=32: 3.28 M tok/s, 128: 3.84 M)
