@@ -562,12 +562,14 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
             for (int j = 0; j < 8; j++) v[j] += b[j];
         }
         if (KIND == EPI_GELU_AUX) {
-            bf16x8 a;
+            if (ep.aux) {           // (inference passes do not keep the pre-activation: one output stream less)
+                bf16x8 a;
 #pragma unroll
-            for (int j = 0; j < 8; j++) a[j] = (bf16_t)v[j];
-            // streamed once, consumed by a later kernel: non-temporal, so the tile does not evict the A panels and the
-            // weight matrix from this XCD's 4 MiB L2 (same-box A/B: c_fc 470 -> 408 us, c_attn 306 -> 279 us)
-            __builtin_nontemporal_store(a, reinterpret_cast<bf16x8*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col));
+                for (int j = 0; j < 8; j++) a[j] = (bf16_t)v[j];
+                // streamed once, consumed by a later kernel: non-temporal, so the tile does not evict the A panels and
+                // the weight matrix from this XCD's 4 MiB L2 (same-box A/B: c_fc 470 -> 408 us, c_attn 306 -> 279 us)
+                __builtin_nontemporal_store(a, reinterpret_cast<bf16x8*>((bf16_t*)ep.aux + (int64_t)row * ep.ldaux + col));
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = gelu_f<false>(v[j]);
         } else if (KIND == EPI_GELUGRAD) {
@@ -606,7 +608,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
 // the kind a launch may use (full tiles only; everything else takes the generic run-time epilogue)
 static int epi_kind_of(const Epilogue& ep, int M, int N, bool swap, bool slabs) {
     if (!swap || slabs || ep.out_fp32 || ep.dbg_nostore || ep.atomic || M % 256 || N % 256) return EPI_GENERIC;
-    if (ep.act == 1) return (ep.aux && !ep.resid && !ep.drop.thr) ? EPI_GELU_AUX : EPI_GENERIC;
+    if (ep.act == 1) return (!ep.resid && !ep.drop.thr) ? EPI_GELU_AUX : EPI_GENERIC;
     if (ep.act == 2) return (!ep.resid && !ep.drop.thr && !ep.bias) ? EPI_GELUGRAD : EPI_GENERIC;
     if (ep.resid) return EPI_RESID;
     return ep.drop.thr ? EPI_GENERIC : EPI_PLAIN;

@@ -469,8 +469,9 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         if (ln)
             CHECK_RC(cmp_k_layernorm_fwd(s, a.r, m->P + o.ln2_g, m->P + o.ln2_b, a.n, a.ln2_mean, a.ln2_rstd, M, E,
                                          m->cfg.ln_eps, dt));
-        CHECK_RC(gemm(m, 0, wt, M, 4 * E, E, a.n, E, W(o.fc_w), wt ? E : 4 * E, a.g, 4 * E, m->P + o.fc_b, 1, a.fc, 4 * E, nullptr, 0,
-                      0, 1, 0.f, 0));                                              // g = gelu(fc)           :504
+        // the pre-activation (a.fc) is only needed by the backward pass
+        CHECK_RC(gemm(m, 0, wt, M, 4 * E, E, a.n, E, W(o.fc_w), wt ? E : 4 * E, a.g, 4 * E, m->P + o.fc_b, 1, training ? a.fc : nullptr,
+                      4 * E, nullptr, 0, 0, 1, 0.f, 0));                                              // g = gelu(fc)           :504
         CHECK_RC(gemm(m, 0, wt, M, E, 4 * E, a.g, 4 * E, W(o.pr_w), wt ? 4 * E : E, m->xs[i + 1], E, m->P + o.pr_b, 0, nullptr, 0, a.r, E,
                       0, 1, pr, drop_stream(step, i, 3)));                         // x = r + dropout(mlp)   :594
     }
