@@ -72,16 +72,24 @@ def load(prefix):
 
 
 class ScalarLog:
-    """Stand-in for tf.summary.create_file_writer (transformer.py:903,933-951): same scalar names and steps,
-    written as JSON lines to `<logdir>/train/scalars.jsonl`."""
+    """tf.summary.create_file_writer + tf.summary.scalar (transformer.py:903,933-951): same scalar names and steps, written
+    twice into `<logdir>/train/`: a TensorBoard event file (composer_amd/tbevents.py) and `scalars.jsonl` (JSON lines)."""
 
     def __init__(self, directory):
+        from composer_amd import tbevents
         self.directory = Path(directory)
         self.directory.mkdir(parents=True, exist_ok=True)
         self._f = open(self.directory / 'scalars.jsonl', 'a')
+        self._events = tbevents.EventFileWriter(self.directory)
 
     def scalar(self, name, value, step):
         self._f.write(json.dumps({'tag': name, 'value': float(value), 'step': int(step)}) + '\n')
+        self._events.scalar(name, value, step)
+
+    def flush(self):
+        self._f.flush()
+        self._events.flush()
 
     def close(self):
         self._f.close()
+        self._events.close()

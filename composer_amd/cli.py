@@ -2,7 +2,8 @@
 
 Mirrors the commands, arguments and defaults of the reference's composer/cli.py (train :516-589, evaluate :591-615,
 generate :617-680, make-config :69-78, summary :424-440) with the TensorFlow model replaced by the HIP one.  Out of
-scope: the MusicRNN model type, MIDI preprocessing/synthesis, TFRecord export.
+scope: the MusicRNN model type, MIDI preprocessing/synthesis.  `export-dataset` (:346-380) and
+`.tfrecord` dataset paths (:232-268) go through composer_amd.tfrecord.
 Documented divergences: `--temperature 0` means greedy argmax (the reference divides by the temperature, cli.py:671);
 besides the reference's MIDI prompt (`--prompt`, read by composer_amd.midi instead of pretty_midi) a prompt can be given
 as event ids (`--prompt-ids` / `--prompt-data`), and an output path ending in `.data` gets event ids instead of a MIDI
@@ -20,6 +21,7 @@ import numpy as np
 
 from . import config as cfgmod
 from . import dataset as ds
+from . import tfrecord
 from .transformer import ModelSaveFrequencyMode, Transformer
 
 
@@ -83,13 +85,26 @@ def create_model(model_type, config, **kwargs):
 
 def get_dataset(model_type, dataset_path, config, mode='', max_files=None, shuffle_files=True, shuffle_dataset=True,
                 rank=0, world_size=1, seed=0):
-    """cli.py:185-276 for directory datasets (`<root>/{train,test}/**/*.data`)."""
+    """cli.py:185-276: a directory dataset (`<root>/{train,test}/**/*.data`) or an exported `.tfrecord` file."""
     if mode not in ('train', 'test', ''):
         raise ValueError('\'{}\' is an invalid dataset mode! Must be one of: \'train\', \'test\', or none.'.format(mode))
     p = Path(dataset_path)
     if not p.is_dir():
-        logging.error('\'{}\' is an invalid dataset path! TFRecord datasets are not supported by this build.'.format(p))
-        sys.exit(1)
+        if not p.is_file() or p.suffix != '.tfrecord':                                   # cli.py:232-241
+            logging.error('\'{}\' is an invalid dataset path! The dataset can either be a directory of processed MIDI '
+                          'files or a TFRecord file.'.format(p))
+            sys.exit(1)
+        dataset, header = tfrecord.load_tfrecord_dataset(p, shuffle=shuffle_dataset, seed=seed, rank=rank, world_size=world_size)
+        warning = 'The TFRecord file was probably exported using a different config.'    # cli.py:246-268
+        if header['model_type'] != model_type.value:
+            logging.warning('Model type mismatch when loading \'{}\'. Expected {} but found {}. {}'.format(
+                p, model_type.value, header['model_type'], warning))
+            click.confirm('Do you want to continue? This may cause errors or corrupt the training session.', abort=True)
+        for name, want in (('batch', config.transformer.train.batch_size), ('window', config.transformer.model.window_size)):
+            if header[name + '_size'] != want:
+                logging.error('Expected a {} size of {} but found {}. {}'.format(name, want, header[name + '_size'], warning))
+                sys.exit(1)
+        return dataset
     p = p / mode
     if not p.exists():
         logging.error('Could not get {} dataset since \'{}\' has no {} folder.'.format(mode, dataset_path, mode))
@@ -204,6 +219,24 @@ def train(model_type, dataset_path, logdir, restoredir, config_filepath, epochs,
                 show_progress_bar=show_progress_bar and rank == 0, max_steps=max_steps)
     if rank == 0 and model_logdir is not None:
         click.echo(str(model_logdir))
+
+
+@cli.command('export-dataset')
+@click.argument('model-type', type=EnumType(ModelType, False))
+@click.argument('preprocessed-path')
+@click.argument('output-path')
+@click.option('-c', '--config', 'config_filepath', default=None)
+@click.option('--use-generator/--no-use-generator', default=False, help='Accepted for compatibility.')
+@click.option('--max-files', default=None, type=int)
+def export_dataset(model_type, preprocessed_path, output_path, config_filepath, use_generator, max_files):
+    """Exports a processed dataset input pipeline as a TFRecord file (cli.py:346-380): the unshuffled batches of the
+    `.data` files under PREPROCESSED-PATH, windowed and batched by the config."""
+    _require_transformer(model_type)
+    config = cfgmod.get(config_filepath or get_default_config())
+    dataset = get_dataset(model_type, preprocessed_path, config, shuffle_dataset=False, max_files=max_files)
+    logging.info('Loading dataset and writing to TFRecord. This make take a while...')
+    n = tfrecord.export_dataset(dataset, output_path, model_type.value)
+    logging.info('Finished exporting \'{}\' as a TFRecord: \'{}\' ({} batches)'.format(preprocessed_path, output_path, n))
 
 
 @cli.command()

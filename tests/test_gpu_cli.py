@@ -92,3 +92,46 @@ def test_c1_train_evaluate_generate(tmp_path):
     reread = nt.NoteSequence.from_midi(tmp_path / "gen" / "song.mid", ignore_drums=False)
     keep = [n for n in direct.notes if n.velocity > 0 and round(n.end * 0.44) > round(n.start * 0.44)]
     assert sorted((n.pitch, n.velocity) for n in reread.notes) == sorted((n.pitch, n.velocity) for n in keep)
+
+
+def test_train_from_tfrecord_matches_directory_and_logs_events(tmp_path):
+    """`export-dataset` then `train <file>.tfrecord` (cli.py:232-268, 346-380): the exported batches are the directory
+    pipeline's unshuffled batches, training from the file runs one step per batch, and the TensorBoard event file holds
+    the same scalars as scalars.jsonl (transformer.py:933-951)."""
+    import glob
+    import json
+    from composer_amd import cli, dataset as D, tbevents
+    root = tmp_path / "data"
+    (root / "train").mkdir(parents=True)
+    D.write_synthetic_data_file(root / "train" / "a.data", 4 * 2 * 129 + 50, seed=21)      # 4 batches of 2 windows of 129
+    cfg = yaml.safe_load(open(cli.get_default_config()))
+    cfg["transformer"]["model"].update(window_size=128, decoder_layers_count=2)
+    cfg["transformer"]["train"]["batch_size"] = 2
+    cfg["transformer"]["runtime"] = {"dtype": "fp32", "seed": 5}
+    cfg_path = tmp_path / "cfg.yml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    r = CliRunner()
+    rec = tmp_path / "train.tfrecord"
+    res = r.invoke(cli.cli, ["export-dataset", "transformer", str(root / "train"), str(rec), "-c", str(cfg_path)], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+
+    def run(dataset, logs):
+        res = r.invoke(cli.cli, ["train", "transformer", str(dataset), "--logdir", str(logs), "-c", str(cfg_path), "-e", "1",
+                                 "--no-show-progress-bar"], catch_exceptions=False)
+        assert res.exit_code == 0, res.output
+        (d,) = list(logs.iterdir())
+        return d, [json.loads(l) for l in (d / "train" / "scalars.jsonl").read_text().strip().split("\n")]
+
+    d1, s1 = run(rec, tmp_path / "logs_rec")
+    losses = [s["value"] for s in s1 if s["tag"] == "loss"]
+    assert len(losses) == 4 and all(np.isfinite(losses))
+    (path,) = glob.glob(str(d1 / "train" / "events.out.tfevents.*"))
+    version, ev = tbevents.read_scalars(path)
+    assert version == "brain.Event:2"
+    assert [(t, st) for t, st, _, _ in ev] == [(s["tag"], s["step"]) for s in s1]
+    assert np.allclose([v for _, _, v, _ in ev], [s["value"] for s in s1], rtol=1e-6)
+    from composer_amd import tfrecord
+    got, _ = tfrecord.load_tfrecord_dataset(rec, shuffle=False)
+    files = D.get_processed_files(root / "train")
+    want = D.load_dataset(files, 2, 128, shuffle=False)
+    assert [x.tobytes() for x, _ in got] == [x.tobytes() for x, _ in want]

@@ -36,7 +36,7 @@ use_layer_normalization: true
 def test_cli_commands_and_defaults():
     r = CliRunner()
     out = r.invoke(cli.cli, ["--help"]).output
-    for cmd in ("train", "evaluate", "generate", "make-config", "summary"):
+    for cmd in ("train", "evaluate", "generate", "make-config", "summary", "export-dataset"):
         assert cmd in out
     h = r.invoke(cli.cli, ["train", "--help"]).output
     for opt in ("--logdir", "--restoredir", "--config", "--epochs", "--max-files", "--save-freq-mode", "--save-freq",
