@@ -57,6 +57,14 @@ template <typename T> using frag_t = typename AT<T>::frag;
 // every softmax/rescale touch of an accumulator (measured: ~40% of the loop's vector instructions).
 template <typename T, int D> struct Occ {
     static constexpr int MINW = (std::is_same<T, float>::value && D == 128) ? 1 : 2;
+    // forward and dQ, bf16 heads up to 64 wide: 3 waves/SIMD (168 registers; dQ lands on 168-170 by itself, and 170
+    // already rounds up to a 2-wave allocation).  Left at 2, hipcc's scheduler spends the spare
+    // registers on a longer software pipeline (213) and the lost occupancy costs more than the schedule gains; at 4
+    // (128 registers) it spills ~120 registers inside the key loop (measured: 2.2x slower).
+#ifndef ATTN_MINW_Q
+#define ATTN_MINW_Q 3
+#endif
+    static constexpr int MINW_Q = (std::is_same<T, bf16_t>::value && D <= 64) ? ATTN_MINW_Q : MINW;
 };
 
 template <typename T, int D> struct Geo {
@@ -228,10 +236,38 @@ __device__ __forceinline__ float max16(const f32x16& s) {
     return max3(max3(a, b, c), max3(d, e, s[15]), a);
 }
 
+// Packed-f32 forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 process two values per lane-instruction): the softmax
+// loops are VALU-bound (D = 64: ~4 vector cycles per MFMA cycle), and hipcc leaves these element loops scalar.
+__device__ __forceinline__ f32x2 pair_of(const f32x16& v, int r) { return f32x2{v[r], v[r + 1]}; }
+// p = exp2(s * c - m) on all 16 values; returns the sum of the results as two partial sums
+__device__ __forceinline__ f32x2 exp2_scaled16(f32x16& s, float c, float negm, f32x2 sum) {
+    const f32x2 cv = {c, c}, mv = {negm, negm};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 a = __builtin_elementwise_fma(pair_of(s, r), cv, mv);
+        const f32x2 p = {fast_exp2(a[0]), fast_exp2(a[1])};
+        sum += p;
+        s[r] = p[0];
+        s[r + 1] = p[1];
+    }
+    return sum;
+}
+// Keeps hipcc from sinking a select below the bf16 conversion: it rewrites cvt(select(c, p, 0)) as
+// select(c, cvt(p), 0), which turns 8 two-value v_cvt_pk_bf16_f32 into 16 single conversions plus 8 v_perm_b32.
+__device__ __forceinline__ void pin16(f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float x = v[r];
+        asm("" : "+v"(x));
+        v[r] = x;
+    }
+}
+
 // Dropout keep-test on the 16 values of one 32-key sub-tile with the QUERY on the lane (forward, dQ): the four
 // registers 4*g4..4*g4+3 hold consecutive keys, so they share the xor base and use the four fixed 24-bit multipliers
 // (v_mul_u32_u24 is full rate; v_mul_lo_u32 is quarter rate).  Dropped entries become 0; the 1/(1-p) scale is applied
 // ONCE to the kernel's output instead of per element.
+template <bool PIN = false>
 __device__ __forceinline__ void mask16_qlane(f32x16& v, uint32_t rowh, int k0, int h, uint32_t thr) {
     const uint32_t gg = ((uint32_t)(k0 >> 2) + (uint32_t)h) * ATTN_G;
 #pragma unroll
@@ -242,6 +278,7 @@ __device__ __forceinline__ void mask16_qlane(f32x16& v, uint32_t rowh, int k0, i
         v[4 * g4 + 2] = (__umul24(x, ATTN_C2) >= thr) ? v[4 * g4 + 2] : 0.f;
         v[4 * g4 + 3] = (__umul24(x, ATTN_C3) >= thr) ? v[4 * g4 + 3] : 0.f;
     }
+    if (PIN) pin16(v);
 }
 
 // store a transposed accumulator tile Y^T[d][row] (d in registers, row on the lane) to out[row][d0 + d]
@@ -337,7 +374,7 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by) {
 // forward.  grid ((nb+1)/2, B*H), 256 threads: wave w owns query rows [qb*128 + 32w, +32)
 // =================================================================================================
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
                                                                           float* __restrict__ lse, int Tn, int H,
                                                                           float scale, DropCfg drop) {
     using G = Geo<T, D>;
@@ -382,7 +419,11 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
         sk.store(Kb, tid);
         sv.store(Kb + IMG, tid);
         __syncthreads();
-        for (int kt0 = 0, it = 0; kt0 < kv_end; kt0 += 64, it++) {
+        // One 64-key tile.  `interior` (compile time) = the tile lies below the diagonal for EVERY wave of the workgroup:
+        // that instance has no branch around an accumulating MFMA.  (With the skip/mask branches of the general form in
+        // the only loop, hipcc carried the O^T accumulators through 64 v_mov_b64 per pair of tiles -- MFMA into a copy,
+        // copy back at the join -- and waited out the MFMA pipeline before the copies.)
+        auto tile = [&](auto interior, const int kt0, const int it) __attribute__((always_inline)) {
             const T* Ks = Kb + (it & 1) * 2 * IMG;
             const T* Vs = Ks + IMG;
             const bool more = kt0 + 64 < kv_end;
@@ -393,7 +434,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
             // Fast path (throughput mode): all 64 keys of the tile are at or below every query of this wave -> no
             // masking; both 32-key sub-tiles go through ONE softmax step: 8 score MFMAs back to back, one row-max exchange
             // and one rescale vote per 64 keys, 32 exponentials, 8 PV MFMAs.
-            const bool full64 = !EXACT && (kt0 + 63 <= q0w) && (kt0 + 64 <= Tn);      // wave-uniform
+            const bool full64 = decltype(interior)::value || (!EXACT && (kt0 + 63 <= q0w) && (kt0 + 64 <= Tn));   // wave-uniform
             if (full64) {
                 f32x16 s0, s1;
 #pragma unroll
@@ -412,20 +453,13 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
                     m = mnew;
                 }
                 const float mc = m * c2;
-                float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float p0 = fast_exp2(fmaf(s0[r], c2, -mc));
-                    const float p1 = fast_exp2(fmaf(s1[r], c2, -mc));
-                    ps0 += p0;
-                    ps1 += p1;
-                    s0[r] = p0;
-                    s1[r] = p1;
-                }
-                lsum += ps0 + ps1;
+                f32x2 ps = {0.f, 0.f};
+                ps = exp2_scaled16(s0, c2, -mc, ps);
+                ps = exp2_scaled16(s1, c2, -mc, ps);
+                lsum += ps[0] + ps[1];
                 if constexpr (DROP) {
-                    mask16_qlane(s0, rowh, kt0, h, drop.thr);
-                    mask16_qlane(s1, rowh, kt0 + 32, h, drop.thr);
+                    mask16_qlane<true>(s0, rowh, kt0, h, drop.thr);
+                    mask16_qlane<true>(s1, rowh, kt0 + 32, h, drop.thr);
                 }
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) {
@@ -492,19 +526,10 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
                         m = mnew;
                     }
                     const float mc = m * c2;
-                    float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        float p0 = fast_exp2(fmaf(s[r], c2, -mc));
-                        float p1 = fast_exp2(fmaf(s[r + 1], c2, -mc));
-                        ps0 += p0;
-                        ps1 += p1;
-                        s[r] = p0;
-                        s[r + 1] = p1;
-                    }
-                    lsum += ps0 + ps1;
+                    const f32x2 ps = exp2_scaled16(s, c2, -mc, f32x2{0.f, 0.f});
+                    lsum += ps[0] + ps[1];
                 }
-                if constexpr (DROP) mask16_qlane(s, rowh, k0, h, drop.thr);
+                if constexpr (DROP) mask16_qlane<true>(s, rowh, k0, h, drop.thr);
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) oacc[dt] = mma_acc_b<T, D>(Vs, 32 * sub, dt, s, lane, oacc[dt]);
             }
@@ -514,7 +539,11 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
                 sv.store(nbuf + IMG, tid);
             }
             __syncthreads();
-        }
+        };
+        int kt0 = 0, it = 0;
+        const int interior_end = EXACT ? 0 : qb * 128;                 // keys below every query row of the block
+        for (; kt0 < interior_end; kt0 += 64, it++) tile(std::true_type{}, kt0, it);
+        for (; kt0 < kv_end; kt0 += 64, it++) tile(std::false_type{}, kt0, it);
         const float ltot = half_sum(lsum);
         const float inv = (DROP ? drop.scale : 1.0f) / ltot;
 #pragma unroll
@@ -528,7 +557,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_fwd_kernel(const 
 // With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
 // =================================================================================================
 template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, (Occ<T, D>::MINW))
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q))
 void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                                          const T* __restrict__ d_o,
                                                                          const float* __restrict__ lse,

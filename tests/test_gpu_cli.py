@@ -115,8 +115,8 @@ def test_train_from_tfrecord_matches_directory_and_logs_events(tmp_path):
     res = r.invoke(cli.cli, ["export-dataset", "transformer", str(root / "train"), str(rec), "-c", str(cfg_path)], catch_exceptions=False)
     assert res.exit_code == 0, res.output
 
-    def run(dataset, logs):
-        res = r.invoke(cli.cli, ["train", "transformer", str(dataset), "--logdir", str(logs), "-c", str(cfg_path), "-e", "1",
+    def run(dataset, logs):            # `-e 2` is ONE pass: the epoch counter starts at 1 (transformer.py:907)
+        res = r.invoke(cli.cli, ["train", "transformer", str(dataset), "--logdir", str(logs), "-c", str(cfg_path), "-e", "2",
                                  "--no-show-progress-bar"], catch_exceptions=False)
         assert res.exit_code == 0, res.output
         (d,) = list(logs.iterdir())
