@@ -2,9 +2,10 @@
 models/__init__.py:66-90): `<logdir>/{checkpoint, ckpt-N.*}` with a `checkpoint` text pointer, at most
 `max_to_keep` checkpoints kept, `latest_checkpoint` resolution.
 
-Payload: one `ckpt-N.npz` (tensor names of the object graph: model/<param>, optimizer/{m,v}/<param>,
-optimizer/iter, step, epoch) instead of a TF TensorBundle -- reading/writing TensorBundle files is a later
-row.  Plain host code: no GPU involved.
+Payload, by `format`: 'npz' (default) = one `ckpt-N.npz` holding the tensors of the object graph (model/<param>,
+optimizer/{m,v}/<param>, optimizer/iter) and step / epoch / save_counter; 'tensorbundle' = the reference's own
+`ckpt-N.index` + `ckpt-N.data-00000-of-00001` pair (composer_amd/tensorbundle.py; not checked against TensorFlow here).
+`load` reads either, whichever exists.  Plain host code: no GPU involved.
 """
 import json
 import os
@@ -17,15 +18,18 @@ import numpy as np
 class CheckpointManager:
     """tf.train.CheckpointManager(checkpoint, directory, max_to_keep) semantics."""
 
-    def __init__(self, directory, max_to_keep=1):
+    def __init__(self, directory, max_to_keep=1, format='npz'):
+        if format not in ('npz', 'tensorbundle'):
+            raise ValueError("checkpoint format must be 'npz' or 'tensorbundle'")
         self.directory = Path(directory) if directory is not None else None
         self.max_to_keep = max_to_keep
+        self.format = format
         self._paths = []
         self._counter = 0
         if self.directory is not None and (self.directory / 'checkpoint').exists():
             txt = (self.directory / 'checkpoint').read_text()
             self._paths = [self.directory / p for p in re.findall(r'all_model_checkpoint_paths: "([^"]+)"', txt)]
-            self._paths = [p for p in self._paths if Path(str(p) + '.npz').exists()]
+            self._paths = [p for p in self._paths if _exists(p)]
             for p in self._paths:
                 m = re.search(r'ckpt-(\d+)$', str(p))
                 if m:
@@ -43,28 +47,44 @@ class CheckpointManager:
         self.directory.mkdir(parents=True, exist_ok=True)
         self._counter += 1                                   # save_counter
         prefix = self.directory / ('ckpt-%d' % self._counter)
-        payload = dict(tensors)
-        payload['__meta__'] = np.frombuffer(json.dumps(dict(meta, save_counter=self._counter)).encode(), dtype=np.uint8)
-        tmp = str(prefix) + '.tmp.npz'
-        np.savez(tmp, **payload)
-        os.replace(tmp, str(prefix) + '.npz')
+        meta = dict(meta, save_counter=self._counter)
+        if self.format == 'tensorbundle':
+            from . import tensorbundle
+            tensorbundle.write_bundle(prefix, tensorbundle.bundle_from_state(tensors, meta))
+        else:
+            payload = dict(tensors)
+            payload['__meta__'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+            tmp = str(prefix) + '.tmp.npz'
+            np.savez(tmp, **payload)
+            os.replace(tmp, str(prefix) + '.npz')
         self._paths.append(prefix)
         if self.max_to_keep:
             while len(self._paths) > self.max_to_keep:
                 old = self._paths.pop(0)
-                try:
-                    os.remove(str(old) + '.npz')
-                except OSError:
-                    pass
+                for ext in _EXTS:
+                    try:
+                        os.remove(str(old) + ext)
+                    except OSError:
+                        pass
         lines = ['model_checkpoint_path: "%s"' % self._paths[-1].name]
         lines += ['all_model_checkpoint_paths: "%s"' % p.name for p in self._paths]
         (self.directory / 'checkpoint').write_text('\n'.join(lines) + '\n')
         return str(prefix)
 
 
+_EXTS = ('.npz', '.index', '.data-00000-of-00001')
+
+
+def _exists(prefix):
+    return Path(str(prefix) + '.npz').exists() or Path(str(prefix) + '.index').exists()
+
+
 def load(prefix):
     if prefix is None:
         raise FileNotFoundError('no checkpoint to restore')
+    if not Path(str(prefix) + '.npz').exists() and Path(str(prefix) + '.index').exists():
+        from . import tensorbundle
+        return tensorbundle.state_from_bundle(tensorbundle.read_bundle(prefix))
     with np.load(str(prefix) + '.npz') as z:
         meta = json.loads(bytes(z['__meta__']).decode()) if '__meta__' in z.files else {}
         tensors = {k: z[k] for k in z.files if k != '__meta__'}

@@ -182,8 +182,10 @@ def summary(model_type, config_filepath):
 @click.option('--max-checkpoints', 'max_checkpoints', type=int, default=3)
 @click.option('--show-progress-bar/--no-show-progress-bar', 'show_progress_bar', default=True)
 @click.option('--max-steps', default=None, type=int, help='Stop after this many steps (not in the reference; for smoke runs).')
+@click.option('--checkpoint-format', type=click.Choice(['npz', 'tensorbundle']), default='npz',
+              help='npz (default) or the reference\'s TensorBundle files (ckpt-N.index / .data-00000-of-00001). Either is restored.')
 def train(model_type, dataset_path, logdir, restoredir, config_filepath, epochs, use_generator, max_files,
-          save_frequency_mode, save_frequency, max_checkpoints, show_progress_bar, max_steps):
+          save_frequency_mode, save_frequency, max_checkpoints, show_progress_bar, max_steps, checkpoint_format):
     """Trains the specified model (cli.py:516-589)."""
     _require_transformer(model_type)
     rank = int(os.environ.get('RANK', '0'))
@@ -216,7 +218,7 @@ def train(model_type, dataset_path, logdir, restoredir, config_filepath, epochs,
     model.train(dataset, input_shape, model_logdir, restoredir=restoredir, epochs=epochs,
                 learning_rate=config.transformer.train.learning_rate, save_frequency_mode=save_frequency_mode,
                 save_frequency=save_frequency, max_checkpoints=max_checkpoints,
-                show_progress_bar=show_progress_bar and rank == 0, max_steps=max_steps)
+                show_progress_bar=show_progress_bar and rank == 0, max_steps=max_steps, checkpoint_format=checkpoint_format)
     if rank == 0 and model_logdir is not None:
         click.echo(str(model_logdir))
 

@@ -353,12 +353,12 @@ class Transformer:
     # ------------------------------------------------------------------ train loop (transformer.py:846-960)
     def train(self, dataset, input_shape, logdir, restoredir=None, epochs=None, learning_rate=1e-3,
               save_frequency_mode=ModelSaveFrequencyMode.EPOCH, save_frequency=1, max_checkpoints=1,
-              show_progress_bar=True, max_steps=None):
+              show_progress_bar=True, max_steps=None, checkpoint_format='npz'):
         logdir = Path(logdir) if logdir is not None else None
         if restoredir is not None:
             logdir = Path(restoredir)                                            # :884-885
         rank = self._dp[0] if self._dp else 0
-        manager = ckpt.CheckpointManager(logdir, max_to_keep=max_checkpoints)   # :890-891
+        manager = ckpt.CheckpointManager(logdir, max_to_keep=max_checkpoints, format=checkpoint_format)   # :890-891
         step, epoch = 1, 1
         if restoredir is not None:                                               # :894-900
             try:
