@@ -15,10 +15,12 @@ for name, E, H, L, T, B in (("C2 6L/8H/d512 seq1024", 512, 8, 6, 1024, 128), ("C
     x = rng.integers(0, V, (B, T), dtype=np.int32); y = rng.integers(0, V, (B, T), dtype=np.int32)
     ds = [(x, y)]
     for _ in range(3): m.evaluate(ds)
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n): m.evaluate(ds)
-    dt = (time.perf_counter() - t0) / n
+    ts = []
+    for _ in range(30):                      # per-call times, median: one host hiccup in a 10-call mean moved it by 15 %
+        t0 = time.perf_counter()
+        m.evaluate(ds)
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
     fl_tok = L * (24 * E * E + 2 * E * T) + 2 * E * V
     tf = B * T * fl_tok / dt / 1e12
     print("%-26s B=%3d: forward %.2f ms, %.2f M tok/s, %.0f TFLOP/s = %.1f %% of 2.5 PF bf16 dense" % (name, B, dt * 1e3, B * T / dt / 1e6, tf, 100 * tf / 2500))
