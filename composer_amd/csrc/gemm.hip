@@ -726,6 +726,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
 //   * same LDS images / swizzles / direct-to-LDS staging / range-checked descriptors as the 128^2 fast path.
 // LDS: 2 stages x (A 32 KiB + B 32 KiB) = 128 KiB.
 // =================================================================================================
+#ifndef GEMM_DIAG
+#define GEMM_DIAG 0
+#endif
 #define H_BM 256
 #define H_BN 256
 #define H_IMG (256 * 64 * 2)
@@ -817,11 +820,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();      // stage 0 of this item has landed (vmcnt(0) rides on the barrier); previous epilogue left stage 1
+        bf16x8 diag_a[2][2][4], diag_b[2][4];       // GEMM_DIAG 2 / 4 only
         for (int kt = kt0; kt < kt1; kt++) {
             const int st = (kt - kt0) & 1;
             const char* ia = smem + st * 2 * H_IMG;
             const char* ib = ia + H_IMG;
-            if (kt + 1 < kt1) {
+            // GEMM_DIAG (measurement builds only -- the results are wrong; tools/ubench/gemm_latency_probe.py):
+            // 1 = no MFMA (fragment reads kept alive), 2 = no LDS fragment reads (the first step's fragments reused),
+            // 3 = no DMA inside the k-loop, 4 = neither reads nor DMA (MFMA + barrier only)
+            if (kt + 1 < kt1 && GEMM_DIAG != 3 && GEMM_DIAG != 4) {
                 char* na = smem + (st ^ 1) * 2 * H_IMG;
                 glds_tile256<A_KM>(ra, na, lda * 2, (kt + 1) * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, (kt + 1) * G_BK, wave, lane);
@@ -829,19 +836,32 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 bf16x8 fb[4];
+                const bool rd = (GEMM_DIAG != 2 && GEMM_DIAG != 4) || kt == kt0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) fb[j] = h_frag<B_KM>(ib, wn * 4 + j, ks, lane);
+                for (int j = 0; j < 4; j++) fb[j] = rd ? h_frag<B_KM>(ib, wn * 4 + j, ks, lane) : diag_b[ks][j];
+                if (GEMM_DIAG == 2 || GEMM_DIAG == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) diag_b[ks][j] = fb[j];
+                }
 #pragma unroll
                 for (int ih = 0; ih < 2; ih++) {
                     bf16x8 fa[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) fa[i] = h_frag<A_KM>(ia, wm * 8 + ih * 4 + i, ks, lane);
+                    for (int i = 0; i < 4; i++) fa[i] = rd ? h_frag<A_KM>(ia, wm * 8 + ih * 4 + i, ks, lane) : diag_a[ks][ih][i];
+                    if (GEMM_DIAG == 2 || GEMM_DIAG == 4) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) diag_a[ks][ih][i] = fa[i];
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
+#if GEMM_DIAG == 1
+                            asm volatile("" ::"v"(fa[i]), "v"(fb[j]));
+#else
                             if (SWAP) acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih * 4 + i][j], 0, 0, 0);
                             else acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[ih * 4 + i][j], 0, 0, 0);
+#endif
                         }
                 }
             }
@@ -1140,7 +1160,10 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                 stamp(11);
                 __builtin_amdgcn_s_barrier();
                 stamp(12);
-                do_issue = t + AHEAD < n;
+#ifndef P4_DIAG
+#define P4_DIAG 0
+#endif
+                do_issue = t + AHEAD < n && P4_DIAG != 3;       // P4_DIAG (measurement builds, wrong results): 1 no MFMA, 3 no DMA in the k-loop
                 stamp(13);
                 if (t + 1 < n) {
 #pragma unroll
@@ -1166,8 +1189,12 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
+#if P4_DIAG == 1
+                    asm volatile("" ::"v"(fa[i]), "v"(fb[j]));
+#else
                     if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#endif
                 }
             }
             if (t + 1 < n) {

@@ -66,6 +66,24 @@ def bench_gemm_fwd():
     gemm_case("fwd mlp c_proj (+bias,+resid)", 0, 1, M, E, 4 * E, bias=True, resid=True)
 
 
+def bench_gemm_diag():
+    """plain [M,K]x[N,K]^T GEMMs of the 256x256 persistent kernel at three depths: per-item time = a + b * (K/64)"""
+    r = []
+    for m, n, k in ((131072, 512, 512), (131072, 512, 2048), (65536, 512, 8192)):
+        us = gemm_case("plain", 0, 1, m, n, k)
+        items_per_cu = (m // 256) * (n // 256) / 256.0
+        r.append((k // 64, us / items_per_cu))
+    b = (r[2][1] - r[1][1]) / (r[2][0] - r[1][0])
+    print("per item: %s us;  b = %.3f us per k-step (K=64), a = %.2f us per item" % (", ".join("K=%d: %.2f" % (64 * ks, t) for ks, t in r), b, r[1][1] - b * r[1][0]))
+
+
+def bench_wgrad_diag():
+    """wgrad shapes (deep-pipeline kernel, split-K): contraction over M tokens"""
+    for nm, m, n in (("wgrad c_fc", E, 4 * E), ("wgrad attn c_proj", E, E)):
+        for sk in (16, 32):
+            gemm_case(nm, 1, 0, m, n, M, splitk=sk, out_fp32=True)
+
+
 def bench_gemm():
     tot = 0
     if os.environ.get("KBENCH_SLABS"):
@@ -143,6 +161,10 @@ if __name__ == "__main__":
         bench_gemm()
     if "gemmfwd" in what:
         bench_gemm_fwd()
+    if "gemmdiag" in what:
+        bench_gemm_diag()
+    if "wgraddiag" in what:
+        bench_wgrad_diag()
     if "attn" in what:
         bench_attn()
     if "ln" in what:
