@@ -5,7 +5,7 @@ import kbench as kb
 import torch
 kb._lib.require_gpu(); torch.zeros(1, device='cuda')
 kb.GFLAGS = 0
-for m in (131072, 32768, 8192, 4096, 1024):
+for m in (65536, 49152, 32768, 24576, 16384, 8192, 1024):
     for k in (2048, 8192):
         us = kb.gemm_case("M=%d" % m, 0, 1, m, 512, k)
         items = (m // 256) * 2
