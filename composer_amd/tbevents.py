@@ -86,10 +86,14 @@ def _record(data: bytes) -> bytes:
 class EventFileWriter:
     """`with summary_log.as_default(): tf.summary.scalar(name, value, step=...)` -> writer.scalar(name, value, step)."""
 
+    _count = 0
+
     def __init__(self, directory, filename_suffix='.v2'):
         os.makedirs(directory, exist_ok=True)
         now = time.time()
-        self.path = os.path.join(str(directory), 'events.out.tfevents.%010d.%s.%d.0%s' % (int(now), socket.gethostname(), os.getpid(), filename_suffix))
+        EventFileWriter._count += 1               # TensorFlow's per-process writer uid: two writers opened within one second stay apart
+        self.path = os.path.join(str(directory), 'events.out.tfevents.%010d.%s.%d.%d%s' % (
+            int(now), socket.gethostname(), os.getpid(), EventFileWriter._count - 1, filename_suffix))
         self._f = open(self.path, 'ab')
         self._f.write(_record(_event(now, step=0, file_version='brain.Event:2')))
         self._f.flush()
