@@ -301,7 +301,7 @@ def attn_ref(qkv, B, T, H, D, keep=None, p=0.0):
 
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
-@pytest.mark.parametrize("B,T,H,D", [(2, 33, 4, 16), (1, 64, 2, 32), (2, 200, 2, 64), (1, 130, 1, 128), (1, 256, 3, 64)])
+@pytest.mark.parametrize("B,T,H,D", [(2, 33, 4, 16), (1, 64, 2, 32), (2, 200, 2, 64), (1, 130, 1, 128), (1, 256, 3, 64), (1, 333, 2, 64), (1, 520, 1, 32)])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
     E = H * D
