@@ -827,11 +827,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             const char* ib = ia + H_IMG;
             // GEMM_DIAG (measurement builds only -- the results are wrong; tools/ubench/gemm_latency_probe.py):
             // 1 = no MFMA (fragment reads kept alive), 2 = no LDS fragment reads (the first step's fragments reused),
-            // 3 = no DMA inside the k-loop, 4 = neither reads nor DMA (MFMA + barrier only)
+            // 3 = no DMA inside the k-loop, 4 = neither reads nor DMA (MFMA + barrier only), 5 = as 1 with TWO stage loads per step
             if (kt + 1 < kt1 && GEMM_DIAG != 3 && GEMM_DIAG != 4) {
                 char* na = smem + (st ^ 1) * 2 * H_IMG;
                 glds_tile256<A_KM>(ra, na, lda * 2, (kt + 1) * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, (kt + 1) * G_BK, wave, lane);
+#if GEMM_DIAG == 5
+                // bandwidth probe: a second, different slab per step into the same buffer -> 128 KiB in flight per CU
+                const int k2 = (kt + 1 + (kt1 - kt0) / 2) % (kt1 - kt0) + kt0;
+                glds_tile256<A_KM>(ra, na, lda * 2, k2 * G_BK, wave, lane);
+                glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, k2 * G_BK, wave, lane);
+#endif
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-#if GEMM_DIAG == 1
+#if GEMM_DIAG == 1 || GEMM_DIAG == 5
                             asm volatile("" ::"v"(fa[i]), "v"(fb[j]));
 #else
                             if (SWAP) acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih * 4 + i][j], 0, 0, 0);
