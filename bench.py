@@ -3,19 +3,27 @@
 [RCCL all-reduce] + Adam) on synthetic int32 MIDI-event sequences, BASELINE.json's metric:
 "MIDI-event tokens/sec (train, seq=1024)".
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4]
 
-Workload (BASELINE config 2/3): 6L/8H/d512 decoder, window 1024, B=128 sequences per GPU (weak scaling; --batch to change),
-bf16 activations with fp32 master weights/accumulation, dropout 0.1 (default_config.yml:39-40), lr 1e-3.
+With --gpus N > 1 and no launcher environment, this process starts `python -m torch.distributed.run` with N ranks of
+itself (before anything touches the GPU), forwards rank 0's JSON line and exits with the launcher's status; under a
+launcher (RANK/WORLD_SIZE set) it is one of the ranks.
+
+Workloads: c2 (default; BASELINE configs 2/3) 6L/8H/d512, window 1024, B=128 sequences per GPU;
+c4 (BASELINE config 4) 12L/12H/d768, window 2048, B=32 per GPU.  Weak scaling (--batch is per GPU).  bf16 activations
+with fp32 master weights/accumulation, dropout 0.1 (default_config.yml:39-40), Adam lr 1e-3.
 Inputs are generated up front and live in HBM before the timed region.
 
 One JSON line on rank 0 with `roofline` (live HIP-event timing of the dominant kernel class inside the timed
-region) and `cpu_baseline` (the numpy oracle, float32, on the host cores, bounded sample; N=1 only).
+region), `cpu_baseline` (the CPU restatement of the reference path on the host cores, bounded sample; N=1 only) and
+`decode` (BASELINE config 5, with its own memory roofline).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,8 +34,12 @@ sys.path.insert(0, ROOT)
 # RCCL / cross-process GPU memory sharing on this pool needs dmabuf IPC (the image exports it; keep it if a launcher dropped it)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-V, E, H, L, W, T = 390, 512, 8, 6, 1024, 1024
-B_PER_GPU = 128       # per-GPU batch: not fixed by BASELINE; sweep in DESIGN.md section 7 (B=32: 3.28 M tok/s, 128: 3.84 M)
+V = 390
+CONFIGS = {
+    # name: (E, H, L, W=T, default B per GPU; not fixed by BASELINE -- sweep in DESIGN.md section 7)
+    "c2": dict(E=512, H=8, L=6, T=1024, B=128, label="6L/8H/d512"),
+    "c4": dict(E=768, H=12, L=12, T=2048, B=32, label="12L/12H/d768"),
+}
 LR = 1e-3
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -43,7 +55,7 @@ KERNEL_CLASSES = {
 }
 
 
-def pmc_traffic(kernel_class, batch):
+def pmc_traffic(kernel_class, tokens, cfg_name):
     """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/hbm_traffic.json, made by
     tools/profile_round.sh + tools/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, gfx950
     correction applied).  Counters cannot be read from inside this process; None when the file does not cover the run."""
@@ -51,7 +63,7 @@ def pmc_traffic(kernel_class, batch):
         doc = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     except Exception:
         return None
-    if kernel_class != 0 or batch * T != doc.get("tokens_per_launch"):
+    if kernel_class != 0 or cfg_name != doc.get("config", "c2") or tokens != doc.get("tokens_per_launch"):
         return None
     return doc.get("class0_forward_gemm_mean_bytes_per_launch")
 
@@ -72,54 +84,109 @@ class stdout_to_stderr:
         return False
 
 
-def flops_per_token_train():
+def flops_per_token_train(E, L, T):
     fwd = L * (24 * E * E + 2 * E * T) + 2 * E * V          # causal attention counted on the unmasked half
     return 3 * fwd
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (numpy, float32, BLAS threads = host cores) on the same workload shape with B=1:
-    forward + backward + Adam steps until ~seconds_budget of CPU work."""
+def cpu_baseline(cf, seconds_budget=24.0):
+    """The reference path restated for the CPU, timed on the host cores: train steps (fwd + bwd + Keras Adam, float32,
+    dropout off) of (a) the torch restatement (oracle/torch_restatement.py: torch CPU ops + autograd, scores materialised
+    like the reference's TF eager path) and (b) the numpy oracle, at the batch that fits the time budget; the faster of
+    the two is reported."""
     from oracle import transformer_oracle as O          # cpu_baseline leg only
+    E, H, L, T = cf["E"], cf["H"], cf["L"], cf["T"]
+    cfg = O.Config(V, E, T, L, H)
+    params = O.init_params(V, E, T, L, seed=0, dtype=np.float32)
+    rng = np.random.default_rng(1234)
+    results = []
+
+    def run(name, make, Bc, budget, cores):
+        eng = make()
+        x, y = O.synthetic_batch(rng, V, Bc, T)
+        t0 = time.time()
+        eng(x, y)                                       # warm-up (thread pools, page faults)
+        warm = time.time() - t0
+        n, t0 = 0, time.time()
+        while True:
+            eng(x, y)
+            n += 1
+            if time.time() - t0 > max(1.5, budget - warm) or n >= 12:
+                break
+        dt = time.time() - t0
+        results.append({"value": Bc * T * n / dt, "unit": "tokens/s", "cores": int(cores), "kind": "port",
+                        "sample": "%d train steps (fwd+bwd+Adam, float32, dropout off) of the %s at B=%d, T=%d, %s"
+                                  % (n, name, Bc, T, cf["label"])})
+
+    try:
+        import torch
+        from oracle.torch_restatement import TorchTrainer
+        cores = torch.get_num_threads()
+        for Bc in ((2, 8) if cores >= 32 else (1,)):
+            def mk():
+                tr = TorchTrainer(cfg, params)
+                return lambda x, y: tr.train_step(x, y, LR)
+            run("torch-CPU restatement of transformer.py", mk, Bc, seconds_budget * 0.4, cores)
+    except Exception as e:                              # torch CPU ops unavailable: numpy leg only
+        print("cpu_baseline: torch leg failed: %r" % (e,), file=sys.stderr)
     try:
         from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+        ncores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
     except Exception:
-        cores = os.cpu_count() or 1
-    params = O.init_params(V, E, W, L, seed=0, dtype=np.float32)
-    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params, dtype=np.float32)
-    rng = np.random.default_rng(1234)
-    Bc = 1
-    x, y = O.synthetic_batch(rng, V, Bc, T)
-    t0 = time.time()
-    orc.train_step(x, y, LR, training=False)            # warm-up (BLAS thread pools, page faults)
-    warm = time.time() - t0
-    n, t0 = 0, time.time()
-    while True:
-        orc.train_step(x, y, LR, training=False)
-        n += 1
-        if time.time() - t0 > max(2.0, seconds_budget - warm) or n >= 8:
-            break
-    dt = time.time() - t0
-    return {"value": Bc * T * n / dt, "unit": "tokens/s", "cores": int(cores), "kind": "port",
-            "sample": "%d train steps (fwd+bwd+Adam, dropout off) of the numpy float32 oracle at B=%d, T=%d, 6L/8H/d512"
-                      % (n, Bc, T)}
+        ncores = os.cpu_count() or 1
+
+    def mk_np():
+        orc = O.OracleTransformer(cfg, params, dtype=np.float32)
+        return lambda x, y: orc.train_step(x, y, LR, training=False)
+    run("numpy oracle", mk_np, 1, seconds_budget * 0.2, ncores)
+    best = max(results, key=lambda r: r["value"])
+    best["others"] = [{"value": r["value"], "sample": r["sample"]} for r in results if r is not best]
+    return best
 
 
 def decode_bench(device):
     """BASELINE config 5: generate 1024 tokens at temperature 1.0 from a 10-id prompt, KV cache + hipGraph per-token
-    step, same 6L/8H/d512 model with window 2048 (prompt + length must fit the wpe table)."""
+    step, the 6L/8H/d512 model with window 2048 (prompt + length must fit the wpe table).  Roofline: the bytes one
+    token step must read (fp32 decode weights: every parameter except the unused wpe rows, plus the K/V cache rows up
+    to the current position) / time, against the HBM peak (the set fits the 256 MiB Infinity Cache)."""
     from composer_amd.transformer import Transformer
-    m = Transformer(V, E, 2048, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="fp32", seed=0,
+    E, H, L, W = 512, 8, 6, 2048
+    P0, N = 10, 1024
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="fp32", seed=0,
                     max_batch=1, max_seq=64, device=device)
-    prompt = np.random.default_rng(0).integers(0, V, 10)
+    prompt = np.random.default_rng(0).integers(0, V, P0)
     m.generate(prompt, 32, temperature=1.0, mode="kv", seed=1)               # warm-up
-    t0 = time.perf_counter()
-    m.generate(prompt, 1024, temperature=1.0, mode="kv", seed=1)
-    dt = time.perf_counter() - t0
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m.generate(prompt, N, temperature=1.0, mode="kv", seed=1)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    nparam = sum(int(np.prod(m.parameter_shape(n))) for n in m.parameter_names)
     m.close()
+    weight_bytes = 4 * (nparam - W * E + E)
+    mean_pos = P0 + (N - 1) / 2.0
+    kv_bytes = 4 * (2 * L * mean_pos * E + 2 * L * E)
+    bpt = weight_bytes + kv_bytes
+    gbs = bpt / (best / N) / 1e9
     return {"metric": "decode tokens/sec (generate len=1024, temp=1.0, batch 1, KV cache + hipGraph)",
-            "value": 1024 / dt, "unit": "tokens/s", "us_per_token": 1e6 * dt / 1024, "dtype": "f32"}
+            "value": N / best, "unit": "tokens/s", "us_per_token": 1e6 * best / N, "dtype": "f32",
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "bytes_per_token": bpt, "traffic": None,
+                         "note": "fp32 weights %.1f MB + mean K/V cache read %.2f MB per token" % (weight_bytes / 1e6, kv_bytes / 1e6)}}
+
+
+def self_launch(args):
+    """--gpus N>1 without a launcher: run N ranks of this file under torch.distributed.run as a CHILD process (this parent
+    has not touched the GPU), forward their stdout/stderr, return the launcher's exit status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -127,7 +194,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="sequences per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default: the config's)")
     ap.add_argument("--roofline-kernel", type=int, default=0, help="kernel class timed live (see KERNEL_CLASSES)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
@@ -137,29 +205,35 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(self_launch(args))
+    if args.gpus != world and under_launcher:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
 
     import torch
     import torch.distributed as dist
     from composer_amd.transformer import Transformer
     from composer_amd import _lib
 
-    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
-    if world > 1 or under_launcher:
+    cf = CONFIGS[args.config]
+    E, H, L, T = cf["E"], cf["H"], cf["L"], cf["T"]
+    W = T
+    if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():
             dist.init_process_group("gloo", rank=rank, world_size=world)     # bootstrap + timing only; gradients go over RCCL
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d, but %d HIP device(s) are visible"
+                         % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    Bq = args.batch
+    Bq = args.batch or cf["B"]
     model = Transformer(V, E, W, L, H, attention_dropout_rate=args.dropout, residual_dropout_rate=args.dropout,
                         dtype="bf16", seed=1000 + rank, max_batch=Bq, max_seq=T, device=local_rank)
     model.initialize_parameters(0)                  # identical replicas
-    if world > 1 or under_launcher:      # a 1-rank launch exercises the same RCCL path (buckets, side stream, 1/N scale)
+    if under_launcher:      # every launched run (also 1 rank) takes the RCCL path: buckets, side stream, 1/N scale
         with stdout_to_stderr():
             uid = [Transformer.new_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
@@ -192,10 +266,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    model.synchronize()
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
+    fence()
     dt = time.perf_counter() - t0
     ms, n_launch, work = C.c_double(), C.c_int64(), C.c_double()
     lib.cmp_prof_end(C.byref(ms), C.byref(n_launch), C.byref(work))
@@ -213,7 +284,7 @@ def main():
             if bound == "mfma":
                 achieved = work.value / (ms.value * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args.roofline_kernel, Bq)}
+                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args.roofline_kernel, Bq * T, args.config)}
                 if roof["traffic"] is not None:
                     roof["traffic_note"] = ("HBM-side bytes per launch (mean of the four per-layer forward GEMMs), rocprofv3 PMC "
                                             "FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json; algorithmic bytes 740 MB")
@@ -226,21 +297,23 @@ def main():
                          "algorithmic_per_launch": work.value / n_launch.value})
         else:
             roof = None
+        fpt = flops_per_token_train(E, L, T)
         out = {
-            "metric": "MIDI-event tokens/sec (train, seq=1024)", "value": value, "unit": "tokens/s",
+            "metric": "MIDI-event tokens/sec (train, seq=%d)" % T, "value": value, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "6L/8H/d512 Transformer train step, seq=1024, B=%d/GPU, dropout %.2f, Adam lr 1e-3, "
-                                   "synthetic int32 event ids (vocab 390), random-init weights" % (Bq, args.dropout),
+            "config": {"workload": "%s Transformer train step, seq=%d, B=%d/GPU, dropout %.2f, Adam lr 1e-3, "
+                                   "synthetic int32 event ids (vocab 390), random-init weights"
+                                   % (cf["label"], T, Bq, args.dropout),
                        "global_batch": world * Bq, "seq_len": T, "parallelism": "dp%d" % world,
                        "tokens_per_step": world * Bq * T},
-            "model_tflops": value * flops_per_token_train() / 1e12,
-            "model_mfma_frac": value * flops_per_token_train() / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "model_tflops": value * fpt / 1e12,
+            "model_mfma_frac": value * fpt / 1e12 / (PEAK_BF16_TFLOPS * world),
             "final_loss": loss,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cf)
         else:
             out["cpu_baseline"] = None
     model.close()

@@ -86,3 +86,18 @@ def test_scalar_log_names(tmp_path):
     s.scalar("loss", 1.5, 1); s.scalar("epoch_accuracy", 0.25, 2); s.close()
     lines = (tmp_path / "train" / "scalars.jsonl").read_text().strip().split("\n")
     assert '"tag": "loss"' in lines[0] and '"step": 2' in lines[1]
+
+
+def test_bench_self_launches_n_ranks_and_fails_cleanly_without_gpus():
+    """`python bench.py --gpus 2` (the driver's SCALE command shape) must start two ranks of itself under
+    torch.distributed.run before touching the GPU; in this GPU-less container each rank then stops with a clear
+    message and the parent forwards the launcher's non-zero status (no hang, no traceback from the parent)."""
+    import subprocess, sys
+    if __import__("torch").cuda.is_available():
+        pytest.skip("GPU present: the ranks would run the real benchmark")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank 0 needs GPU 0" in r.stderr and "rank 1 needs GPU 1" in r.stderr
+    assert r.stdout.strip() == ""

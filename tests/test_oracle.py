@@ -11,37 +11,7 @@ from oracle import transformer_oracle as O
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def torch_forward(P, x, cfg, past_len=0):
-    """Independent restatement with torch ops + autograd (no shared code with the oracle)."""
-    B, T = x.shape
-    E, H, D = cfg.E, cfg.H, cfg.D
-    pos = torch.arange(past_len, past_len + T)
-    h = P["wte/weight"][x] + P["wpe/embeddings"][pos]
-    for i in range(cfg.L):
-        p = "decoder_blocks/%d/" % i
-        if cfg.use_ln:
-            h = torch.nn.functional.layer_norm(h, (E,), P[p + "ln_1/gamma"], P[p + "ln_1/beta"], cfg.eps)
-        qkv = h.reshape(-1, E) @ P[p + "attn/c_attn/weight"] + P[p + "attn/c_attn/bias"]
-        q, k, v = qkv.reshape(B, T, 3 * E).split(E, dim=2)
-        q, k, v = [t.reshape(B, T, H, D).permute(0, 2, 1, 3) for t in (q, k, v)]
-        w = q @ k.transpose(-1, -2)
-        if cfg.scale:
-            w = w * (1.0 / math.sqrt(D))
-        b = torch.tril(torch.ones(T, T, dtype=w.dtype))
-        w = w * b - 1e4 * (1 - b)
-        w = torch.softmax(w, -1)
-        a = (w @ v).permute(0, 2, 1, 3).reshape(B, T, E)
-        a = (a.reshape(-1, E) @ P[p + "attn/c_proj/weight"] + P[p + "attn/c_proj/bias"]).reshape(B, T, E)
-        h = h + a
-        m = h
-        if cfg.use_ln:
-            m = torch.nn.functional.layer_norm(h, (E,), P[p + "ln_2/gamma"], P[p + "ln_2/beta"], cfg.eps)
-        f = m.reshape(-1, E) @ P[p + "mlp/c_fc/weight"] + P[p + "mlp/c_fc/bias"]
-        f = 0.5 * f * (1 + torch.tanh(math.sqrt(2 / math.pi) * (f + 0.044715 * f ** 3)))
-        f = (f @ P[p + "mlp/c_proj/weight"] + P[p + "mlp/c_proj/bias"]).reshape(B, T, E)
-        h = h + f
-    h = torch.nn.functional.layer_norm(h, (E,), P["ln_f/gamma"], P["ln_f/beta"], cfg.eps)
-    return h @ P["wte/weight"].T
+from oracle.torch_restatement import forward as torch_forward, TorchTrainer   # independent restatement (no shared code)
 
 
 @pytest.mark.parametrize("E,H,L,T,use_ln", [(32, 4, 2, 16, True), (64, 4, 2, 33, True), (32, 2, 1, 8, False)])
@@ -69,6 +39,24 @@ def test_oracle_matches_torch_autograd(E, H, L, T, use_ln):
             continue
         g = P[k].grad.numpy()
         assert np.allclose(G[k], g, atol=1e-12, rtol=1e-9), k
+
+
+def test_torch_trainer_follows_the_oracle_train_steps():
+    """The torch restatement's full train step (autograd + Keras Adam), which bench.py times as the CPU baseline, tracks
+    the numpy oracle's for 3 steps in float64."""
+    V, E, H, L, W, T, B = 390, 32, 4, 2, 24, 20, 2
+    cfg = O.Config(V, E, W, L, H)
+    params = O.init_params(V, E, W, L, seed=6)
+    rng = np.random.default_rng(7)
+    orc = O.OracleTransformer(cfg, params)
+    tt = TorchTrainer(cfg, params, dtype=torch.float64)
+    for s in range(3):
+        x, y = O.synthetic_batch(rng, V, B, T)
+        lo, ao = orc.train_step(x, y, 1e-3, training=False)
+        lt, at = tt.train_step(x, y, 1e-3)
+        assert abs(lo - lt) < 1e-10 and abs(ao - at) < 1e-12
+    for k in params:
+        assert np.allclose(orc.p[k], tt.P[k].detach().numpy(), atol=1e-12), k
 
 
 def test_adam_is_keras_formulation():
