@@ -45,6 +45,7 @@ SIGNATURES = {
     "cmp_dp_unique_id": (_i, [_P]),
     "cmp_dp_init": (_i, [_P, _i, _i, _P]),
     "cmp_dp_allreduce_test": (_i, [_P, _P, _i]),
+    "cmp_dp_set_gemm_cus": (_i, [_P, _i]),
     "cmp_model_create": (_i, [_P, C.POINTER(ModelCfg), C.POINTER(_P)]),
     "cmp_model_destroy": (_i, [_P]),
     "cmp_param_count": (_i, [_P, C.POINTER(_i)]),
@@ -56,10 +57,13 @@ SIGNATURES = {
     "cmp_train_step": (_i, [_P, _P, _P, _i, _i, _f, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_train_step_dev": (_i, [_P, _P, _P, _i, _i, _f]),
     "cmp_train_metrics": (_i, [_P, C.POINTER(_f), C.POINTER(_f)]),
+    "cmp_train_step_async": (_i, [_P, _P, _P, _i, _i, _f, C.POINTER(_i64)]),
+    "cmp_train_metrics_wait": (_i, [_P, _i64, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_loss_and_grads": (_i, [_P, _P, _P, _i, _i, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_eval_step": (_i, [_P, _P, _P, _i, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
     "cmp_present_get": (_i, [_P, _i, _i, _i, _P]),
     "cmp_forward_logits": (_i, [_P, _P, _i, _i, _P]),
+    "cmp_forward": (_i, [_P, _P, _i, _i, _i, _P, _i, _P]),
     "cmp_decode_begin": (_i, [_P, _P, _i, _i, _f, _u64]),
     "cmp_decode_steps": (_i, [_P, _i, _P]),
     "cmp_prof_begin": (_i, [_i]),

@@ -292,6 +292,15 @@ def generate(model_type, restoredir, output_filepath, prompt, prompt_ids, prompt
         raise NotImplementedError()                              # cli.py:642-643
     x = x[:prompt_length]                                        # cli.py:649
     model.reset_states()
+    if decode_mode == 'kv-cache' and len(x) + generate_length - 1 > config.transformer.model.window_size:
+        # position ids would run past the wpe table (transformer.py:675-679,786).  The reference's own loop never feeds
+        # `past` back (cli.py:663-676), which is why it can emit any length: fall back to exactly that loop.
+        logging.warning('prompt ({}) + length ({}) - 1 exceeds window_size ({}): the KV-cache decode would index past the '
+                        'position table; using --decode-mode reference-literal (the reference\'s loop) instead. With the '
+                        'KV cache at most --length {} fits.'.format(
+                            len(x), generate_length, config.transformer.model.window_size,
+                            config.transformer.model.window_size - len(x) + 1))
+        decode_mode = 'reference-literal'
     ids = model.generate(x, generate_length, temperature=temperature, mode=decode_mode)
     all_ids = list(x) + ids.tolist()                             # prompt + generated (cli.py:676)
     out = Path(output_filepath)

@@ -911,22 +911,30 @@ extern "C" int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse
     else { DISPATCH_D(float, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
 }
 
-// One-shot: the next cmp_k_attn_bwd also adds the column sums of [dQ | dK | dV] to out[0..3E) (the c_attn bias gradient).
-static float* g_attn_bias_next = nullptr;
+// One-shot for the kernel-level tests that call cmp_k_attn_bwd directly (per calling thread): the next cmp_k_attn_bwd also
+// adds the column sums of [dQ | dK | dV] to out[0..3E) (the c_attn bias gradient).  The model driver passes the pointer to
+// attn_bwd_run itself.
+static thread_local float* t_attn_bias_next = nullptr;
 extern "C" int cmp_attn_bwd_bias_next(float* out) {
-    g_attn_bias_next = out;
+    t_attn_bias_next = out;
     return CMP_OK;
 }
 
 extern "C" int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
                               float* delta_ws, void* dqkv, int B, int T, int H, int D, int scale, int dtype,
                               float p_drop, uint64_t seed, uint32_t rng_stream) {
+    float* bias_grad = t_attn_bias_next;
+    t_attn_bias_next = nullptr;
+    return attn_bwd_run(stream, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, D, scale, dtype, p_drop, seed, rng_stream, bias_grad);
+}
+
+int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
+                 int B, int T, int H, int D, int scale, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
+                 float* bias_grad) {
     if (B * T == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     float sc = scale ? 1.0f / sqrtf((float)D) : 1.0f;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
-    float* bias_grad = g_attn_bias_next;
-    g_attn_bias_next = nullptr;
     if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }
     else { DISPATCH_D(float, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }
 }

@@ -44,11 +44,28 @@ void cmp_set_error(const char* fmt, ...);
 #define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
 
 // live per-kernel-class timing (cmp_prof_begin / cmp_prof_end, model.hip)
-extern int g_prof_cls;
+extern thread_local int g_prof_cls;
 void prof_start(int cls, hipStream_t s);
 void prof_stop(int cls, hipStream_t s, double work);
 #define PROF_START(cls, s) do { if (g_prof_cls == (cls)) prof_start((cls), (s)); } while (0)
 #define PROF_STOP(cls, s, work) do { if (g_prof_cls == (cls)) prof_stop((cls), (s), (work)); } while (0)
+
+// Per-launch extras of the GEMM launcher (gemm.hip: gemm_run) that the C ABI's cmp_k_gemm does not carry.  The model driver
+// fills one per call, so nothing about a launch lives in process-wide state.
+struct GemmExtra {
+    float* colsum = nullptr;     // also add the column sums of the output to colsum[0..N) (the bias gradient that goes with an
+                                 // input-gradient GEMM); fused into the epilogue where possible, else a colsum pass after it
+    float* slab_ws = nullptr;    // split-K: per-split fp32 partial tiles + fixed-order reduce instead of float atomics
+    size_t slab_bytes = 0;
+    int role = -1;               // cmp_prof_* timing class: 0 forward, 1 dgrad, 2 wgrad, -1 = by operand layout
+    int max_wgs = 0;             // cap on the persistent kernels' grid (CUs left to a concurrent RCCL kernel); 0 = all 256
+};
+int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* Bm, int ldb,
+             void* C, int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
+             int splitk, float p_drop, uint64_t seed, uint32_t rng_stream, int flags, const GemmExtra& ex);
+int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
+                 int B, int T, int H, int D, int scale, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
+                 float* bias_grad);
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -313,7 +313,9 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict
         float v = z[c];
         if (temperature > 0.f) {
             unsigned hsh = drop_hash(seed, 0xC0FFEEu + ctr, (uint64_t)c);
-            float u = ((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+            // 23 bits + 0.5: every value is exact in fp32 and strictly inside (0,1) (24 bits + 0.5 rounds up to 1.0 for the
+            // top value: -log(-log(1)) = +inf, one token in ~43 000 would ignore its logit)
+            float u = ((float)(hsh >> 9) + 0.5f) * (1.0f / 8388608.0f);
             v = v / temperature - logf(-logf(u));
         }
         if (v > best) { best = v; arg = c; }

@@ -1312,7 +1312,7 @@ extern "C" int cmp_gemm_set_stamps(void* dev_buf) {
 }
 template <bool A_KM, bool B_KM, int NWM, int NST>
 static bool launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
-                          void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride) {
+                          void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride, int max_wgs) {
     static bool attr_set = false;
     constexpr int BM = 128 * NWM;
     const size_t smem = (size_t)NST * (BM * P_BK * 2 + 256 * P_BK * 2);
@@ -1322,7 +1322,7 @@ static bool launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
         attr_set = true;
     }
     const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, BM);
-    const int grid = std::min(ntiles * nsplit, NWM == 1 ? 512 : 256);
+    const int grid = std::min(ntiles * nsplit, NWM == 1 ? 2 * max_wgs : max_wgs);   // persistent: one (two) workgroups per CU in use
     if constexpr (A_KM && !B_KM) {
         // the forward layout carries the compile-time epilogue kinds (and the diagnostic timeline build)
         const int kind = epi_kind_of(ep, M, N, swap, slab_stride != 0);
@@ -1358,9 +1358,9 @@ static bool launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
 }
 template <bool A_KM, bool B_KM>
 static bool launch_p4(hipStream_t s, int cfg, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
-                      void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride) {
-    if (cfg == 1) return launch_p4_cfg<A_KM, B_KM, 1, 3>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, slab_stride);
-    return launch_p4_cfg<A_KM, B_KM, 2, 4>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, slab_stride);
+                      void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride, int max_wgs) {
+    if (cfg == 1) return launch_p4_cfg<A_KM, B_KM, 1, 3>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, slab_stride, max_wgs);
+    return launch_p4_cfg<A_KM, B_KM, 2, 4>(s, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, slab_stride, max_wgs);
 }
 
 // C[i] += sum_s slab[s][i]  (fixed order: reproducible); 16 bytes per lane
@@ -1375,21 +1375,19 @@ __global__ void gemm_slab_reduce_kernel(const float* __restrict__ slab, float* _
 // One-shot: the NEXT cmp_k_gemm also adds the column sums of its output to out[0..N) (bias gradient of the layer that
 // produced the GEMM's input gradient).  Fused into the epilogue where a compile-time kind runs (saves re-reading the
 // output: 84 us per layer for the [M,4E] MLP gradient at B=128), otherwise a cmp_k_colsum pass after the launch.
-static int g_gemm_role = -1;
-int gemm_set_role(int role) {       // internal (model.hip): profiler class of the following cmp_k_gemm calls; -1 = by layout
-    g_gemm_role = role;
-    return CMP_OK;
-}
-static float* g_colsum_next = nullptr;
+// The model driver (model.hip) passes these per launch in a GemmExtra (model.h) -- no state outlives a call.  The two
+// C-ABI arming calls below exist for the kernel-level tests / micro-benchmarks that drive cmp_k_gemm directly; their state is
+// per calling thread and consumed by that thread's next cmp_k_gemm.
+static thread_local float* t_colsum_next = nullptr;
 extern "C" int cmp_gemm_colsum_next(float* out) {
-    g_colsum_next = out;
+    t_colsum_next = out;
     return CMP_OK;
 }
-static float* g_slab_ws = nullptr;       // split-K workspace registered by the model (cmp_gemm_set_workspace)
-static size_t g_slab_bytes = 0;
+static thread_local float* t_slab_ws = nullptr;       // split-K workspace for this thread's cmp_k_gemm calls
+static thread_local size_t t_slab_bytes = 0;
 extern "C" int cmp_gemm_set_workspace(void* ws, int64_t bytes) {
-    g_slab_ws = (float*)ws;
-    g_slab_bytes = ws ? (size_t)bytes : 0;
+    t_slab_ws = (float*)ws;
+    t_slab_bytes = ws ? (size_t)bytes : 0;
     return CMP_OK;
 }
 
@@ -1437,9 +1435,25 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
                           const void* Bm, int ldb, void* C, int ldc, const float* bias, int act, void* aux, int ldaux,
                           const void* resid, int ldr, int out_fp32, int splitk, float p_drop, uint64_t seed,
                           uint32_t rng_stream, int flags) {
+    GemmExtra ex;
+    ex.colsum = t_colsum_next;
+    t_colsum_next = nullptr;
+    ex.slab_ws = t_slab_ws;
+    ex.slab_bytes = t_slab_bytes;
+    return gemm_run(stream, dtype, ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr, out_fp32, splitk,
+                    p_drop, seed, rng_stream, flags, ex);
+}
+
+int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* Bm, int ldb,
+             void* C, int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
+             int splitk, float p_drop, uint64_t seed, uint32_t rng_stream, int flags, const GemmExtra& ex) {
     if (M == 0 || N == 0) return CMP_OK;
     CMP_REQUIRE(K > 0, "gemm: K must be positive");
     hipStream_t s = (hipStream_t)stream;
+    const int max_wgs = ex.max_wgs > 0 ? std::min(ex.max_wgs, 256) : 256;
+    float* const g_slab_ws = ex.slab_ws;
+    const size_t g_slab_bytes = ex.slab_ws ? ex.slab_bytes : 0;
+    const int g_gemm_role = ex.role;
     Epilogue ep;
     ep.bias = bias;
     ep.act = act;
@@ -1451,8 +1465,7 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
     ep.atomic = splitk > 1 ? 1 : 0;
     ep.dbg_nostore = (flags & 64) ? 1 : 0;
     ep.colsum = nullptr;
-    float* colsum_out = g_colsum_next;
-    g_colsum_next = nullptr;
+    float* colsum_out = ex.colsum;
     if (colsum_out) CMP_REQUIRE(!out_fp32 && splitk <= 1, "gemm: column sums need a plain (non split-K) output in the compute dtype");
     bool colsum_fused = false;
     ep.drop = make_drop(p_drop, seed, rng_stream);
@@ -1512,10 +1525,10 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
             void* Cdst = slabs ? (void*)g_slab_ws : C;
             const int64_t sstride = slabs ? (int64_t)M * N : 0;
             ep2.colsum = colsum_out;
-            if (!ta && !tb) colsum_fused = launch_p4<true, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
-            else if (!ta && tb) colsum_fused = launch_p4<true, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
-            else if (ta && !tb) colsum_fused = launch_p4<false, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
-            else colsum_fused = launch_p4<false, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride);
+            if (!ta && !tb) colsum_fused = launch_p4<true, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride, max_wgs);
+            else if (!ta && tb) colsum_fused = launch_p4<true, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride, max_wgs);
+            else if (ta && !tb) colsum_fused = launch_p4<false, false>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride, max_wgs);
+            else colsum_fused = launch_p4<false, true>(s, cfg, swap, M, N, K, a, lda, b, ldb, Cdst, ldc, ep2, per32, nsplit, sstride, max_wgs);
             if (slabs) {
                 const int64_t n4 = (int64_t)M * N / 4;
                 gemm_slab_reduce_kernel<<<(int)std::min<int64_t>(cdiv64(n4, 256), 2048), 256, 0, s>>>(g_slab_ws, (float*)C, n4, n4, nsplit);
@@ -1523,7 +1536,7 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
         } else if (big) {
             const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, H_BM);
             const int nsplit = cdiv(nk, per);
-            const int g1 = std::min(ntiles * nsplit, 256);
+            const int g1 = std::min(ntiles * nsplit, max_wgs);
             const bool swap = !ep.atomic;
             ep.colsum = colsum_out;
             if (!ta && !tb) colsum_fused = launch_256<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);

@@ -13,6 +13,8 @@ struct Metrics {
     long long correct;
     float loss_mean;
     float acc;
+    int bad_ids;        // ids outside [0, V) seen (and clamped) by the device-pointer entry points
+    int pad;
 };
 
 #define NCCL_CHECK(expr)                                                                         \
@@ -36,6 +38,8 @@ struct cmp_ctx {
     hipStream_t comm_stream = nullptr;  // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    int gemm_max_wgs = 0;               // cap on the persistent GEMM grids while a communicator exists (0 = all CUs)
+    hipStream_t copy_stream = nullptr;  // host -> device id uploads of the pipelined train loop
 };
 
 struct ParamInfo {
@@ -95,11 +99,23 @@ struct cmp_model {
     int64_t slab_bytes = 0;
     Metrics* metrics = nullptr;        // device
     Metrics* metrics_host = nullptr;   // pinned
-    float* dp_metrics = nullptr;       // device [2] for the cross-rank mean
+    float* dp_metrics = nullptr;       // device [4]: {loss mean, accuracy, 1, 0} summed over ranks (3-float all-reduce)
+    // pipelined train loop (cmp_train_step_async): STAGES pinned id buffers + device copies, one metrics slot and two
+    // events per in-flight step
+    static constexpr int STAGES = 3;
+    int32_t* stage_host[STAGES] = {nullptr, nullptr, nullptr};     // pinned [2][cap tokens]: x then y
+    int32_t* stage_dev[STAGES] = {nullptr, nullptr, nullptr};
+    Metrics* stage_metrics = nullptr;                              // pinned [STAGES]
+    hipEvent_t stage_uploaded[STAGES] = {nullptr, nullptr, nullptr};
+    hipEvent_t stage_done[STAGES] = {nullptr, nullptr, nullptr};
+    int64_t stage_ticket[STAGES] = {-1, -1, -1};
+    int64_t next_ticket = 0;
+    int64_t stage_cap = 0;             // tokens per staging buffer
+    int lastB = 0, lastT = 0, last_past = 0;   // shape of the forward pass whose activations are held (cmp_present_get)
     std::vector<hipEvent_t> bucket_ev; // L+2 events
-    hipEvent_t comm_done = nullptr;
+    hipEvent_t comm_done = nullptr, metrics_ev = nullptr;
     DecodeState* dec = nullptr;
-    int gemm_role = -1;                // profiler class announced to cmp_k_gemm (0 while the forward pass is enqueued)
+    int gemm_role = -1;                // profiler class of the GEMMs being enqueued (0 while the forward pass is)
 
     const void* w(int64_t off) const { return dtype == CMP_BF16 ? (const void*)(S + off) : (const void*)(P + off); }
 };
@@ -116,9 +132,8 @@ template <typename Tp> static int dev_alloc(cmp_model* m, Tp** p, size_t bytes) 
 // elementwise.hip
 int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics);
 int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n);
-int gemm_set_role(int role);      // gemm.hip: profiler class override (0 forward, 1 dgrad, 2 wgrad, -1 by layout)
 // model.hip
 int ensure_workspace(cmp_model* m, int B, int T);
-int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step);
+int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step, int past_len = 0);
 // decode.hip
 void decode_state_free(DecodeState* d);

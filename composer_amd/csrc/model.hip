@@ -33,10 +33,11 @@ extern "C" int cmp_device_count(void) {
 // -------------------------------------------------------------------------------------------------
 // live kernel timing
 // -------------------------------------------------------------------------------------------------
-int g_prof_cls = -1;
-static std::vector<hipEvent_t> g_prof_ev;     // start/stop pairs
-static size_t g_prof_used = 0;
-static double g_prof_work = 0.0;
+// (benchmark instrumentation: one timed class at a time, armed and read by the thread that runs the steps)
+thread_local int g_prof_cls = -1;
+static thread_local std::vector<hipEvent_t> g_prof_ev;     // start/stop pairs
+static thread_local size_t g_prof_used = 0;
+static thread_local double g_prof_work = 0.0;
 void prof_start(int, hipStream_t s) {
     if (g_prof_used + 2 > g_prof_ev.size()) {
         for (int i = 0; i < 256; i++) {
@@ -86,8 +87,17 @@ extern "C" int cmp_ctx_create(int device, cmp_ctx** out) {
     HIP_CHECK(hipSetDevice(device));
     cmp_ctx* c = new cmp_ctx();
     c->device = device;
+    // the RCCL stream gets the highest priority the device offers: its kernels are short and latency-bound, and every
+    // compute kernel is a persistent launch that would otherwise keep them waiting for a full kernel
+    int prio_lo = 0, prio_hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_hi));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    {
+        const char* e = getenv("COMPOSER_DP_GEMM_CUS");
+        if (e && atoi(e) > 0) c->gemm_max_wgs = atoi(e);
+    }
     *out = c;
     return CMP_OK;
 }
@@ -98,11 +108,13 @@ extern "C" int cmp_ctx_destroy(cmp_ctx* c) {
     if (c->comm) ncclCommDestroy(c->comm);
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->comm_stream);
+    hipStreamDestroy(c->copy_stream);
     delete c;
     return CMP_OK;
 }
 extern "C" int cmp_sync(cmp_ctx* c) {
     CMP_REQUIRE(c, "sync: ctx is null");
+    HIP_CHECK(hipStreamSynchronize(c->copy_stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     HIP_CHECK(hipStreamSynchronize(c->comm_stream));
     return CMP_OK;
@@ -126,6 +138,11 @@ extern "C" int cmp_dp_init(cmp_ctx* c, int rank, int nranks, const void* id128) 
     NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
     c->rank = rank;
     c->nranks = nranks;
+    return CMP_OK;
+}
+extern "C" int cmp_dp_set_gemm_cus(cmp_ctx* c, int cus) {
+    CMP_REQUIRE(c && cus >= 0 && cus <= 256, "dp_set_gemm_cus: 0 (all) .. 256");
+    c->gemm_max_wgs = cus;
     return CMP_OK;
 }
 extern "C" int cmp_dp_allreduce_test(cmp_ctx* c, float* host_inout, int n) {
@@ -233,6 +250,7 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     m->bucket_ev.resize(L + 2);
     for (auto& e : m->bucket_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&m->comm_done, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&m->metrics_ev, hipEventDisableTiming));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *out = m;
     return CMP_OK;
@@ -245,8 +263,15 @@ extern "C" int cmp_model_destroy(cmp_model* m) {
     if (m->dec) decode_state_free(m->dec);
     for (void* p : m->allocs) hipFree(p);
     if (m->metrics_host) hipHostFree(m->metrics_host);
+    if (m->stage_metrics) hipHostFree(m->stage_metrics);
+    for (int i = 0; i < cmp_model::STAGES; i++) {
+        if (m->stage_host[i]) hipHostFree(m->stage_host[i]);
+        if (m->stage_uploaded[i]) hipEventDestroy(m->stage_uploaded[i]);
+        if (m->stage_done[i]) hipEventDestroy(m->stage_done[i]);
+    }
     for (auto& e : m->bucket_ev) hipEventDestroy(e);
     if (m->comm_done) hipEventDestroy(m->comm_done);
+    if (m->metrics_ev) hipEventDestroy(m->metrics_ev);
     delete m;
     return CMP_OK;
 }
@@ -401,21 +426,27 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const bf16_t* __
                                                                 const WDesc* __restrict__ desc) {
     __shared__ bf16_t tile[32][34];
     const WDesc d = desc[blockIdx.y];
-    const int tiles_c = d.cols >> 5, ntiles = (d.rows >> 5) * tiles_c;
+    const int tiles_c = (d.cols + 31) >> 5, ntiles = ((d.rows + 31) >> 5) * tiles_c;     // edge tiles are bounds-checked (E % 32 != 0)
     if ((int)blockIdx.x >= ntiles) return;
     const int tr = (blockIdx.x / tiles_c) << 5, tc = (blockIdx.x % tiles_c) << 5;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
     const bf16_t* src = S + d.off;
     bf16_t* dst = ST + d.off;
 #pragma unroll
-    for (int j = 0; j < 4; j++) tile[ty + 8 * j][tx] = src[(int64_t)(tr + ty + 8 * j) * d.cols + tc + tx];
+    for (int j = 0; j < 4; j++) {
+        const int r = tr + ty + 8 * j, c = tc + tx;
+        tile[ty + 8 * j][tx] = (r < d.rows && c < d.cols) ? src[(int64_t)r * d.cols + c] : (bf16_t)0.f;
+    }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; j++) dst[(int64_t)(tc + ty + 8 * j) * d.rows + tr + tx] = tile[tx][ty + 8 * j];
+    for (int j = 0; j < 4; j++) {
+        const int c = tc + ty + 8 * j, r = tr + tx;
+        if (c < d.cols && r < d.rows) dst[(int64_t)c * d.rows + r] = tile[tx][ty + 8 * j];
+    }
 }
 static int refresh_transposed_weights(cmp_model* m) {
     if (!m->ST) return CMP_OK;
-    const int maxtiles = (4 * m->E / 32) * (m->E / 32);
+    const int maxtiles = cdiv(4 * m->E, 32) * cdiv(m->E, 32);
     transpose_weights_kernel<<<dim3(maxtiles, 4 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc);
     KERNEL_CHECK();
     return CMP_OK;
@@ -426,18 +457,43 @@ static int refresh_transposed_weights(cmp_model* m) {
 // -------------------------------------------------------------------------------------------------
 static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                 int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
-                int splitk, float p_drop, uint32_t rng_stream, int flags = 0) {
-    const bool use_slab = splitk > 1 && m->slab != nullptr;
-    if (use_slab) cmp_gemm_set_workspace(m->slab, m->slab_bytes);     // registered only around this launch
-    gemm_set_role(m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1));   // forward announces 0; backward: A^T = wgrad, else dgrad
-    int rc = cmp_k_gemm(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
-                        out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags);
-    if (use_slab) cmp_gemm_set_workspace(nullptr, 0);
-    gemm_set_role(-1);
-    return rc;
+                int splitk, float p_drop, uint32_t rng_stream, int flags = 0, float* colsum = nullptr) {
+    GemmExtra ex;
+    ex.colsum = colsum;
+    if (splitk > 1 && m->slab != nullptr) { ex.slab_ws = (float*)m->slab; ex.slab_bytes = (size_t)m->slab_bytes; }
+    ex.role = m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1);         // forward announces 0; backward: A^T = wgrad, else dgrad
+    ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;              // leave CUs to the concurrent all-reduce kernels
+    return gemm_run(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
+                    out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags, ex);
 }
 
-int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step) {
+// copies rows (b, s0 + t) of src [*, sT rows per batch, src_ld] to rows (b, d0 + t) of dst, w 16-byte vectors per row
+__global__ void rows_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int Tn, int w, int sT, int s0,
+                                 int src_ld, int dT, int d0, int dst_ld) {
+    const int64_t n = (int64_t)B * Tn * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % w);
+        const int t = (int)((i / w) % Tn);
+        const int b = (int)(i / ((int64_t)w * Tn));
+        dst[((int64_t)b * dT + d0 + t) * dst_ld + c] = src[((int64_t)b * sT + s0 + t) * src_ld + c];
+    }
+}
+static int rows_copy(cmp_model* m, const void* src, void* dst, int B, int Tn, int width, int sT, int s0, int src_w, int dT, int d0,
+                     int dst_w) {
+    const int es = (int)m->es, w = width * es / 16;
+    const int64_t n = (int64_t)B * Tn * w;
+    rows_copy_kernel<<<(int)std::min<int64_t>(cdiv64(n, 256), 4096), 256, 0, m->ctx->stream>>>(
+        (const uint4*)src, (uint4*)dst, B, Tn, w, sT, s0, src_w * es / 16, dT, d0, dst_w * es / 16);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+// past_len > 0 is Transformer.call(inputs, past=presents) (transformer.py:735-765, 423-426): the T new tokens sit at
+// positions past_len .. past_len+T-1; every layer's K/V of the first past_len positions were placed into rows [0, past_len)
+// of act[i].qkv viewed as [B, past_len + T, 3E] by cmp_forward, the new rows are appended behind them, the causal attention
+// kernel runs over all past_len + T rows (the mask of transformer.py:290-301 for nd = T, ns = past_len + T is the last T
+// rows of the square one) and the T new output rows are taken out again.
+int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step, int past_len) {
     hipStream_t s = m->ctx->stream;
     struct RoleGuard {
         cmp_model* m;
@@ -448,7 +504,9 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
     const float pr = training ? m->cfg.resid_dropout : 0.f;
     const float pa = training ? m->cfg.attn_dropout : 0.f;
     const bool ln = m->cfg.use_layer_norm != 0;
-    CHECK_RC(cmp_k_embed_fwd(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, 0, dt, pr, m->cfg.seed,
+    const int Tp = past_len, Tt = past_len + T;
+    m->lastB = B; m->lastT = Tt; m->last_past = Tp;
+    CHECK_RC(cmp_k_embed_fwd(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, Tp, dt, pr, m->cfg.seed,
                              drop_stream(step, 0, 0)));
     CHECK_RC(refresh_transposed_weights(m));
     // Conv1D weight operand of the forward GEMMs: [in,out] as stored (fp32 mode), or the transposed bf16 copy (tb = 1)
@@ -460,11 +518,14 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         if (ln)   // transformer.py:583-584 -- the LN output REPLACES the residual stream
             CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[i], m->P + o.ln1_g, m->P + o.ln1_b, a.u, a.ln1_mean, a.ln1_rstd, M, E,
                                          m->cfg.ln_eps, dt));
-        CHECK_RC(gemm(m, 0, wt, M, 3 * E, E, a.u, E, W(o.attn_w), wt ? E : 3 * E, a.qkv, 3 * E, m->P + o.attn_b, 0, nullptr, 0,
-                      nullptr, 0, 0, 1, 0.f, 0));
-        CHECK_RC(cmp_k_attn_fwd(s, a.qkv, a.att, a.lse, B, T, m->H, m->D, m->cfg.scale_attention, dt, pa, m->cfg.seed,
+        CHECK_RC(gemm(m, 0, wt, M, 3 * E, E, a.u, E, W(o.attn_w), wt ? E : 3 * E, Tp ? m->dqkv : a.qkv, 3 * E, m->P + o.attn_b, 0,
+                      nullptr, 0, nullptr, 0, 0, 1, 0.f, 0));
+        if (Tp) CHECK_RC(rows_copy(m, m->dqkv, a.qkv, B, T, 3 * E, T, 0, 3 * E, Tt, Tp, 3 * E));     // concat([past, new]) :423-426
+        CHECK_RC(cmp_k_attn_fwd(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, m->cfg.scale_attention, dt, pa, m->cfg.seed,
                                 drop_stream(step, i, 1)));
-        CHECK_RC(gemm(m, 0, wt, M, E, E, a.att, E, W(o.proj_w), E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
+        const void* att = a.att;
+        if (Tp) { CHECK_RC(rows_copy(m, a.att, m->tmpE, B, T, E, Tt, Tp, E, T, 0, E)); att = m->tmpE; }
+        CHECK_RC(gemm(m, 0, wt, M, E, E, att, E, W(o.proj_w), E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
                       drop_stream(step, i, 2)));                                   // r = u + dropout(proj)  :587
         if (ln)
             CHECK_RC(cmp_k_layernorm_fwd(s, a.r, m->P + o.ln2_g, m->P + o.ln2_b, a.n, a.ln2_mean, a.ln2_rstd, M, E,
@@ -501,9 +562,12 @@ static int wgrad_splits(int K, int M, int N) {
     return std::min(s, std::max(1, K / 256));
 }
 
+// A gradient bucket is complete on the compute stream: all-reduce it on the communication stream behind an event.
+// Runs whenever a communicator exists, also with ONE rank (RCCL then copies in place): the 1-GPU tests and a 1-rank
+// launched bench execute exactly the event / side-stream / ncclAllReduce sequence of the 8-GPU job.
 static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end) {
     cmp_ctx* c = m->ctx;
-    if (c->nranks <= 1 || !c->comm) return CMP_OK;
+    if (!c->comm) return CMP_OK;
     HIP_CHECK(hipEventRecord(m->bucket_ev[ev], c->stream));
     HIP_CHECK(hipStreamWaitEvent(c->comm_stream, m->bucket_ev[ev], 0));
     NCCL_CHECK(ncclAllReduce(m->G + begin, m->G + begin, (size_t)(end - begin), ncclFloat, ncclSum, c->comm, c->comm_stream));
@@ -541,9 +605,8 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         CHECK_RC(gemm(m, 1, 0, 4 * E, E, M, a.g, 4 * E, dmo, E, m->G + o.pr_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, 4 * E, E)), 0.f, 0));
         if (!dmo_ready) CHECK_RC(cmp_k_colsum(s, dmo, E, m->G + o.pr_b, M, E, dt));
-        CHECK_RC(cmp_gemm_colsum_next(m->G + o.fc_b));                             // b_fc grad = column sums of dfc
         CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, dmo, E, m->w(o.pr_w), E, m->dfc, 4 * E, nullptr, 2, a.fc, 4 * E, nullptr, 0, 0, 1,
-                      0.f, 0));                                                    // dfc = (dmo.Wpr^T) * gelu'(fc)
+                      0.f, 0, 0, m->G + o.fc_b));      // dfc = (dmo.Wpr^T) * gelu'(fc); b_fc grad = column sums of dfc
         CHECK_RC(gemm(m, 1, 0, E, 4 * E, M, a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, E, 4 * E)), 0.f, 0));
         if (ln) {
@@ -567,9 +630,8 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         if (!ln) CHECK_RC(cmp_k_colsum(s, dao, E, m->G + o.proj_b, M, E, dt));
         CHECK_RC(gemm(m, 0, 1, M, E, E, dao, E, m->w(o.proj_w), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
                       0));                                                         // datt
-        CHECK_RC(cmp_attn_bwd_bias_next(m->G + o.attn_b));                         // b_attn grad = column sums of dqkv
-        CHECK_RC(cmp_k_attn_bwd(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
-                                dt, pa, m->cfg.seed, drop_stream(step, i, 1)));
+        CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
+                              dt, pa, m->cfg.seed, drop_stream(step, i, 1), m->G + o.attn_b));   // b_attn grad = column sums of dqkv
         CHECK_RC(gemm(m, 1, 0, E, 3 * E, M, a.u, E, m->dqkv, 3 * E, m->G + o.attn_w, 3 * E, nullptr, 0, nullptr, 0, nullptr, 0,
                       1, std::max(2, wgrad_splits(M, E, 3 * E)), 0.f, 0));
         if (ln) {
@@ -594,13 +656,34 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     return CMP_OK;
 }
 
+// metrics across ranks (the reference logs ONE loss per step, transformer.py:929-939): {loss mean, accuracy, 1}
+// of every rank summed by a 3-float all-reduce on the communication stream, divided by the rank count after it
+__global__ void dp_metrics_pack_kernel(const Metrics* __restrict__ mt, float* __restrict__ dp) {
+    if (threadIdx.x == 0) { dp[0] = mt->loss_mean; dp[1] = mt->acc; dp[2] = 1.0f; dp[3] = 0.f; }
+}
+__global__ void dp_metrics_unpack_kernel(Metrics* __restrict__ mt, const float* __restrict__ dp) {
+    if (threadIdx.x == 0 && dp[2] > 0.f) { mt->loss_mean = dp[0] / dp[2]; mt->acc = dp[1] / dp[2]; }
+}
+static int dp_metrics_begin(cmp_model* m) {
+    cmp_ctx* c = m->ctx;
+    if (!c->comm) return CMP_OK;
+    dp_metrics_pack_kernel<<<1, 64, 0, c->stream>>>(m->metrics, m->dp_metrics);
+    KERNEL_CHECK();
+    HIP_CHECK(hipEventRecord(m->metrics_ev, c->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->comm_stream, m->metrics_ev, 0));
+    NCCL_CHECK(ncclAllReduce(m->dp_metrics, m->dp_metrics, 3, ncclFloat, ncclSum, c->comm, c->comm_stream));
+    return CMP_OK;
+}
+
 static int adam(cmp_model* m, float lr) {
     cmp_ctx* c = m->ctx;
     float gscale = 1.0f;
-    if (c->nranks > 1 && c->comm) {
+    if (c->comm) {
         HIP_CHECK(hipEventRecord(m->comm_done, c->comm_stream));
         HIP_CHECK(hipStreamWaitEvent(c->stream, m->comm_done, 0));
         gscale = 1.0f / (float)c->nranks;       // all-reduce summed: global-batch mean gradient
+        dp_metrics_unpack_kernel<<<1, 64, 0, c->stream>>>(m->metrics, m->dp_metrics);
+        KERNEL_CHECK();
     }
     m->iterations += 1;
     return cmp_k_adam(c->stream, m->P, m->G, m->Am, m->Av, m->S, m->total, lr, 0.9f, 0.999f, 1e-7f, m->iterations, gscale);
@@ -611,15 +694,42 @@ static int fetch_metrics(cmp_model* m) {
     return CMP_OK;
 }
 
+// ids handed over as DEVICE pointers cannot be checked on the host: one pass clamps them into [0, V) (an id outside the
+// table would read / scatter-add outside wte) into the model's own id buffers and counts the offenders; cmp_train_metrics
+// reports a non-zero count as CMP_ERR_INVALID.
+__global__ void sanitize_ids_kernel(const int32_t* __restrict__ x, const int32_t* __restrict__ y, int32_t* __restrict__ xo,
+                                    int32_t* __restrict__ yo, int n, int V, int* __restrict__ bad) {
+    int nbad = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int a = x[i], b = y[i];
+        nbad += (a < 0 || a >= V) + (b < 0 || b >= V);
+        xo[i] = min(max(a, 0), V - 1);
+        yo[i] = min(max(b, 0), V - 1);
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+// the step itself on ids already in HBM and already known to be in range
+static int train_step_enqueue(cmp_model* m, const int32_t* x_dev, const int32_t* y_dev, int B, int T, float lr) {
+    const int64_t step = m->iterations;
+    CHECK_RC(model_forward(m, x_dev, B, T, true, step));
+    CHECK_RC(loss(m, y_dev, B * T, true));
+    CHECK_RC(dp_metrics_begin(m));
+    CHECK_RC(backward(m, x_dev, B, T, step, true));
+    CHECK_RC(adam(m, lr));
+    return CMP_OK;
+}
+
 extern "C" int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, float lr) {
     CMP_REQUIRE(m && x_dev && y_dev, "train_step_dev: null argument");
     HIP_CHECK(hipSetDevice(m->ctx->device));
     CHECK_RC(ensure_workspace(m, B, T));
-    const int64_t step = m->iterations;
-    CHECK_RC(model_forward(m, (const int32_t*)x_dev, B, T, true, step));
-    CHECK_RC(loss(m, (const int32_t*)y_dev, B * T, true));
-    CHECK_RC(backward(m, (const int32_t*)x_dev, B, T, step, true));
-    CHECK_RC(adam(m, lr));
+    hipStream_t s = m->ctx->stream;
+    HIP_CHECK(hipMemsetAsync(&m->metrics->bad_ids, 0, sizeof(int), s));
+    sanitize_ids_kernel<<<std::min(cdiv(B * T, 256), 1024), 256, 0, s>>>((const int32_t*)x_dev, (const int32_t*)y_dev, m->x_dev,
+                                                                         m->y_dev, B * T, m->V, &m->metrics->bad_ids);
+    KERNEL_CHECK();
+    CHECK_RC(train_step_enqueue(m, m->x_dev, m->y_dev, B, T, lr));
     CHECK_RC(fetch_metrics(m));
     return CMP_OK;
 }
@@ -629,13 +739,83 @@ extern "C" int cmp_train_metrics(cmp_model* m, float* loss_out, float* acc_out) 
     HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     if (loss_out) *loss_out = m->metrics_host->loss_mean;
     if (acc_out) *acc_out = m->metrics_host->acc;
+    CMP_REQUIRE(m->metrics_host->bad_ids == 0, "train step: %d token ids outside [0, %d) were passed by device pointer (clamped)",
+                m->metrics_host->bad_ids, m->V);
     return CMP_OK;
 }
 
-static int upload_xy(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T) {
-    CHECK_RC(ensure_workspace(m, B, T));
+static int check_host_ids(cmp_model* m, const int32_t* ids, int64_t n, const char* what) {
+    for (int64_t i = 0; i < n; i++)
+        CMP_REQUIRE(ids[i] >= 0 && ids[i] < m->V, "%s: token id %d at flat index %lld is outside [0, %d)", what, ids[i], (long long)i, m->V);
+    return CMP_OK;
+}
+
+static int upload_xy(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, int past_len = 0) {
+    CHECK_RC(ensure_workspace(m, B, T + past_len));
+    CHECK_RC(check_host_ids(m, x, (int64_t)B * T, "input ids"));
+    if (y) CHECK_RC(check_host_ids(m, y, (int64_t)B * T, "target ids"));
+    HIP_CHECK(hipMemsetAsync(&m->metrics->bad_ids, 0, sizeof(int), m->ctx->stream));
     HIP_CHECK(hipMemcpyAsync(m->x_dev, x, (size_t)B * T * 4, hipMemcpyHostToDevice, m->ctx->stream));
     if (y) HIP_CHECK(hipMemcpyAsync(m->y_dev, y, (size_t)B * T * 4, hipMemcpyHostToDevice, m->ctx->stream));
+    return CMP_OK;
+}
+
+// ---- pipelined host-buffer steps (Transformer.train): the ids of step s+1 are staged in pinned memory and uploaded on a
+// copy stream while step s computes, and a step's metrics are read one or two steps later, so the Python loop never waits
+// for the step it has just submitted (the loop body of transformer.py:914-946 with its logged values unchanged).
+static int ensure_stages(cmp_model* m, int64_t tokens) {
+    if (m->stage_cap >= tokens) return CMP_OK;
+    CMP_REQUIRE(m->stage_cap == 0, "train_step_async: staging was sized for %lld tokens", (long long)m->stage_cap);
+    const int64_t cap = std::max<int64_t>(tokens, (int64_t)m->capB * m->capT);
+    HIP_CHECK(hipHostMalloc((void**)&m->stage_metrics, sizeof(Metrics) * cmp_model::STAGES, hipHostMallocDefault));
+    memset(m->stage_metrics, 0, sizeof(Metrics) * cmp_model::STAGES);
+    for (int i = 0; i < cmp_model::STAGES; i++) {
+        HIP_CHECK(hipHostMalloc((void**)&m->stage_host[i], (size_t)cap * 8, hipHostMallocDefault));
+        CHECK_RC(dev_alloc(m, &m->stage_dev[i], (size_t)cap * 8));
+        HIP_CHECK(hipEventCreateWithFlags(&m->stage_uploaded[i], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&m->stage_done[i], hipEventDisableTiming));
+    }
+    m->stage_cap = cap;
+    return CMP_OK;
+}
+
+extern "C" int cmp_train_step_async(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, float lr, int64_t* ticket) {
+    CMP_REQUIRE(m && x && y && ticket, "train_step_async: null argument");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(ensure_workspace(m, B, T));
+    const int64_t n = (int64_t)B * T;
+    CHECK_RC(ensure_stages(m, n));
+    CHECK_RC(check_host_ids(m, x, n, "input ids"));
+    CHECK_RC(check_host_ids(m, y, n, "target ids"));
+    const int64_t tk = m->next_ticket;
+    const int slot = (int)(tk % cmp_model::STAGES);
+    if (m->stage_ticket[slot] >= 0) HIP_CHECK(hipEventSynchronize(m->stage_done[slot]));    // slot still owned by step tk - STAGES
+    memcpy(m->stage_host[slot], x, (size_t)n * 4);
+    memcpy(m->stage_host[slot] + n, y, (size_t)n * 4);
+    cmp_ctx* c = m->ctx;
+    HIP_CHECK(hipMemcpyAsync(m->stage_dev[slot], m->stage_host[slot], (size_t)n * 8, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_CHECK(hipEventRecord(m->stage_uploaded[slot], c->copy_stream));
+    HIP_CHECK(hipStreamWaitEvent(c->stream, m->stage_uploaded[slot], 0));
+    HIP_CHECK(hipMemsetAsync(&m->metrics->bad_ids, 0, sizeof(int), c->stream));
+    CHECK_RC(train_step_enqueue(m, m->stage_dev[slot], m->stage_dev[slot] + n, B, T, lr));
+    HIP_CHECK(hipMemcpyAsync(&m->stage_metrics[slot], m->metrics, sizeof(Metrics), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(m->metrics_host, m->metrics, sizeof(Metrics), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipEventRecord(m->stage_done[slot], c->stream));
+    m->stage_ticket[slot] = tk;
+    m->next_ticket = tk + 1;
+    *ticket = tk;
+    return CMP_OK;
+}
+
+extern "C" int cmp_train_metrics_wait(cmp_model* m, int64_t ticket, float* loss_out, float* acc_out) {
+    CMP_REQUIRE(m, "train_metrics_wait: null model");
+    const int slot = (int)(ticket % cmp_model::STAGES);
+    CMP_REQUIRE(ticket >= 0 && m->stage_cap > 0 && m->stage_ticket[slot] == ticket,
+                "train_metrics_wait: ticket %lld is not in flight (at most %d steps are)", (long long)ticket, cmp_model::STAGES);
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    HIP_CHECK(hipEventSynchronize(m->stage_done[slot]));
+    if (loss_out) *loss_out = m->stage_metrics[slot].loss_mean;
+    if (acc_out) *acc_out = m->stage_metrics[slot].acc;
     return CMP_OK;
 }
 
@@ -644,7 +824,8 @@ extern "C" int cmp_train_step(cmp_model* m, const int32_t* x, const int32_t* y, 
     CMP_REQUIRE(m && x && y, "train_step: null argument");
     HIP_CHECK(hipSetDevice(m->ctx->device));
     CHECK_RC(upload_xy(m, x, y, B, T));
-    CHECK_RC(cmp_train_step_dev(m, m->x_dev, m->y_dev, B, T, lr));
+    CHECK_RC(train_step_enqueue(m, m->x_dev, m->y_dev, B, T, lr));
+    CHECK_RC(fetch_metrics(m));
     if (loss_out || acc_out) CHECK_RC(cmp_train_metrics(m, loss_out, acc_out));
     return CMP_OK;
 }
@@ -696,7 +877,8 @@ __global__ void present_gather_kernel(const T_* __restrict__ qkv, float* __restr
 extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out) {
     CMP_REQUIRE(m && host_out, "present_get: null argument");
     CMP_REQUIRE(layer >= 0 && layer < m->L, "present_get: layer %d outside [0, %d)", layer, m->L);
-    CMP_REQUIRE(B > 0 && T > 0 && (int64_t)B * T <= (int64_t)m->capB * m->capT && !m->act.empty(), "present_get: no forward pass of shape [%d,%d] is held", B, T);
+    CMP_REQUIRE(B > 0 && T > 0 && !m->act.empty() && B == m->lastB && T == m->lastT,
+                "present_get: the forward pass held is [%d,%d] (batch, past + new positions), not [%d,%d]", m->lastB, m->lastT, B, T);
     HIP_CHECK(hipSetDevice(m->ctx->device));
     const int64_t n = (int64_t)2 * B * m->H * T * m->D;
     float* tmp = nullptr;
@@ -711,13 +893,65 @@ extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* hos
     return CMP_OK;
 }
 
-extern "C" int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logits_out) {
-    CMP_REQUIRE(m && x && logits_out, "forward_logits: null argument");
+// host `past` [2, B, H, Tp, D] (fp32) -> K and V columns of rows [0, Tp) of qkv viewed as [B, Tt, 3E]; the Q columns of those
+// rows are zeroed (their attention outputs are never read)
+template <typename T_>
+__global__ void past_scatter_kernel(const float* __restrict__ in, T_* __restrict__ qkv, int B, int Tp, int Tt, int H, int D) {
+    const int E = H * D;
+    const int64_t n = (int64_t)2 * B * H * Tp * D, nq = (int64_t)B * Tp * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + nq; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n) {
+            const int d = (int)(i % D);
+            const int t = (int)((i / D) % Tp);
+            const int h = (int)((i / ((int64_t)D * Tp)) % H);
+            const int b = (int)((i / ((int64_t)D * Tp * H)) % B);
+            const int kv = (int)(i / ((int64_t)D * Tp * H * B));
+            qkv[((int64_t)b * Tt + t) * 3 * E + (1 + kv) * E + h * D + d] = from_f32<T_>(in[i]);
+        } else {
+            const int64_t j = i - n;
+            const int e = (int)(j % E);
+            const int t = (int)((j / E) % Tp);
+            const int b = (int)(j / ((int64_t)E * Tp));
+            qkv[((int64_t)b * Tt + t) * 3 * E + e] = from_f32<T_>(0.f);
+        }
+    }
+}
+
+extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
+                           float* logits_out) {
+    CMP_REQUIRE(m && x && logits_out, "forward: null argument");
+    CMP_REQUIRE(past_len >= 0 && (past_len == 0 || past != nullptr), "forward: past_len %d without past tensors", past_len);
+    CMP_REQUIRE(!(training && past_len > 0), "forward: training=True together with `past` is not supported");
+    CMP_REQUIRE(T > 0 && T + past_len <= m->W, "forward: positions %d..%d exceed window_size %d (wpe rows, transformer.py:675-679,786)",
+                past_len, past_len + T - 1, m->W);
     HIP_CHECK(hipSetDevice(m->ctx->device));
-    CHECK_RC(upload_xy(m, x, nullptr, B, T));
-    CHECK_RC(model_forward(m, m->x_dev, B, T, false, 0));
+    CHECK_RC(upload_xy(m, x, nullptr, B, T, past_len));
+    hipStream_t s = m->ctx->stream;
+    if (past_len > 0) {
+        const int64_t n = (int64_t)2 * B * m->H * past_len * m->D;
+        float* tmp = nullptr;
+        HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
+        int rc = CMP_OK;
+        for (int i = 0; i < m->L && rc == CMP_OK; i++) {
+            if (!past[i]) { cmp_set_error("forward: past[%d] is null", i); rc = CMP_ERR_INVALID; break; }
+            hipError_t e = hipMemcpyAsync(tmp, past[i], (size_t)n * 4, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) { cmp_set_error("forward: uploading past[%d]: %s", i, hipGetErrorString(e)); rc = CMP_ERR_HIP; break; }
+            const int grid = (int)std::min<int64_t>(cdiv64(n + (int64_t)B * past_len * m->E, 256), 4096);
+            if (m->dtype == CMP_BF16) past_scatter_kernel<bf16_t><<<grid, 256, 0, s>>>(tmp, (bf16_t*)m->act[i].qkv, B, past_len, past_len + T, m->H, m->D);
+            else past_scatter_kernel<float><<<grid, 256, 0, s>>>(tmp, (float*)m->act[i].qkv, B, past_len, past_len + T, m->H, m->D);
+            e = hipStreamSynchronize(s);          // tmp is reused by the next layer's upload
+            if (e != hipSuccess) { cmp_set_error("forward: past scatter: %s", hipGetErrorString(e)); rc = CMP_ERR_HIP; }
+        }
+        (void)hipFree(tmp);
+        CHECK_RC(rc);
+    }
+    CHECK_RC(model_forward(m, m->x_dev, B, T, training != 0, m->iterations, past_len));
     HIP_CHECK(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->ldz * 4, (size_t)m->V * 4, (size_t)B * T,
-                               hipMemcpyDeviceToHost, m->ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+                               hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
     return CMP_OK;
+}
+
+extern "C" int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logits_out) {
+    return cmp_forward(m, x, B, T, 0, nullptr, 0, logits_out);
 }

@@ -194,11 +194,20 @@ class Transformer:
         return total
 
     # ------------------------------------------------------------------ data parallel
-    def init_data_parallel(self, rank, world_size, unique_id):
-        """One rank per GPU; `unique_id` = 128 bytes from rank 0's `new_unique_id()` shared by the launcher."""
+    def init_data_parallel(self, rank, world_size, unique_id, gemm_cus=None):
+        """One rank per GPU; `unique_id` = 128 bytes from rank 0's `new_unique_id()` shared by the launcher.
+        gemm_cus: CUs the persistent GEMM kernels may occupy while gradients are all-reduced (None/0 = all 256)."""
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _lib.check(self._lib.cmp_dp_init(self._ctx, int(rank), int(world_size), buf), 'cmp_dp_init')
+        if gemm_cus:
+            _lib.check(self._lib.cmp_dp_set_gemm_cus(self._ctx, int(gemm_cus)), 'cmp_dp_set_gemm_cus')
         self._dp = (int(rank), int(world_size))
+
+    def all_reduce_sum(self, values):
+        """Sum of a small float vector over the data-parallel ranks (RCCL, cmp_dp_allreduce_test)."""
+        a = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+        _lib.check(self._lib.cmp_dp_allreduce_test(self._ctx, a.ctypes.data_as(C.c_void_p), a.size), 'cmp_dp_allreduce_test')
+        return a
 
     @staticmethod
     def new_unique_id():
@@ -222,22 +231,40 @@ class Transformer:
 
     def __call__(self, inputs, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
                  input_embeddings=None, use_cache=True, training=False):
-        """Transformer.call (transformer.py:696-833) -> (logits [B,T,V] float32, presents)."""
-        if past is not None:
-            raise NotImplementedError('host-supplied `past` is not supported; the KV cache lives on the device: '
-                                      'use generate(..., mode="kv")')
+        """Transformer.call (transformer.py:696-833) -> (logits [B,T,V] float32, presents).
+
+        `past` = an earlier call's presents (L tensors [2,B,H,Tp,D], or the lazy Presents object): only the last input
+        token is used (:735-737), it sits at position Tp (:760-770), its keys/values are appended to `past` (:423-426)
+        and the returned presents hold Tp+1 positions.  `training=True` (:916-917) applies dropout with the masks a train
+        step at the current optimizer iteration would draw."""
         if attention_mask is not None or token_type_ids is not None or position_ids is not None or input_embeddings is not None:
             raise NotImplementedError('attention_mask/token_type_ids/position_ids/input_embeddings are never used by the CLI path')
-        if training:
-            raise NotImplementedError('use train_step()/train() for training-mode passes')
         x = self._ids(inputs)
+        past_len, past_ptrs, keep = 0, None, []
+        if past is not None:
+            if training:
+                raise NotImplementedError('training=True together with `past` is not supported')
+            x = np.ascontiguousarray(x[:, -1:])                                  # transformer.py:735-737
+            past = list(past)
+            if len(past) != self.decoder_layers_count:
+                raise ValueError('past must hold one tensor per decoder block')
+            H, D = self.attention_head_count, self.embedding_size // self.attention_head_count
+            keep = [np.ascontiguousarray(np.asarray(p, dtype=np.float32)) for p in past]
+            past_len = int(keep[0].shape[-2])
+            for p in keep:
+                if p.shape != (2, x.shape[0], H, past_len, D):
+                    raise ValueError('past tensors must be [2, batch, heads, past_len, head_size]; got %s' % (p.shape,))
+            past_ptrs = (C.c_void_p * len(keep))(*[p.ctypes.data for p in keep])
         self._check_ids(x)
         B, T = x.shape
+        if past_len + T > self.window_size:
+            raise IndexError('position %d outside the wpe table (window_size %d, transformer.py:675-679,786)'
+                             % (past_len + T - 1, self.window_size))
         logits = np.empty((B, T, self.vocab_size), np.float32)
-        _lib.check(self._lib.cmp_forward_logits(self._h, x.ctypes.data_as(C.c_void_p), B, T,
-                                                logits.ctypes.data_as(C.c_void_p)), 'cmp_forward_logits')
+        _lib.check(self._lib.cmp_forward(self._h, x.ctypes.data_as(C.c_void_p), B, T, past_len, past_ptrs, int(bool(training)),
+                                         logits.ctypes.data_as(C.c_void_p)), 'cmp_forward')
         if use_cache is True:
-            return logits, Presents(self, B, T)
+            return logits, Presents(self, B, past_len + T)
         return (logits,)
 
     def _fetch_present(self, layer, B, T):
@@ -264,6 +291,24 @@ class Transformer:
         lr = self._learning_rate if learning_rate is None else float(learning_rate)
         _lib.check(self._lib.cmp_train_step_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), B, T, lr), 'cmp_train_step_dev')
 
+    def train_step_async(self, x, y, learning_rate=None):
+        """Submits one train step without waiting for it (ids staged in pinned memory, uploaded on a copy stream behind the
+        previous step); returns a ticket for step_metrics().  At most 3 steps are in flight."""
+        x, y = self._ids(x), self._ids(y)
+        self._check_ids(x); self._check_ids(y)
+        B, T = x.shape
+        lr = self._learning_rate if learning_rate is None else float(learning_rate)
+        ticket = C.c_int64()
+        _lib.check(self._lib.cmp_train_step_async(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), B, T, lr,
+                                                  C.byref(ticket)), 'cmp_train_step_async')
+        return int(ticket.value)
+
+    def step_metrics(self, ticket):
+        """(loss, accuracy) of the step `ticket` was issued for; blocks until that step (not later ones) has finished."""
+        loss, acc = C.c_float(), C.c_float()
+        _lib.check(self._lib.cmp_train_metrics_wait(self._h, int(ticket), C.byref(loss), C.byref(acc)), 'cmp_train_metrics_wait')
+        return loss.value, acc.value
+
     def last_metrics(self):
         loss, acc = C.c_float(), C.c_float()
         _lib.check(self._lib.cmp_train_metrics(self._h, C.byref(loss), C.byref(acc)), 'cmp_train_metrics')
@@ -279,6 +324,7 @@ class Transformer:
     def loss_and_grads(self, x, y):
         """forward(training=True)+backward without the optimizer; gradients via get_parameter(name, KIND_GRAD)."""
         x, y = self._ids(x), self._ids(y)
+        self._check_ids(x); self._check_ids(y)
         B, T = x.shape
         loss, acc = C.c_float(), C.c_float()
         _lib.check(self._lib.cmp_loss_and_grads(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), B, T,
@@ -290,6 +336,7 @@ class Transformer:
         tot, cor, cnt = 0.0, 0, 0
         for x, y in dataset:
             x, y = self._ids(x), self._ids(y)
+            self._check_ids(x); self._check_ids(y)
             B, T = x.shape
             ls, c, n = C.c_double(), C.c_int64(), C.c_int64()
             _lib.check(self._lib.cmp_eval_step(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), B, T,
@@ -382,23 +429,38 @@ class Transformer:
         while (epochs is None or epoch < epochs) and not done:                   # :907 (epoch starts at 1)
             logging.info('Epoch {}'.format(epoch if epochs is None else '{}/{}'.format(epoch, epochs)))
             ep_loss, ep_correct, ep_n, t0 = 0.0, 0.0, 0, time.time()
+            # The device runs up to two steps ahead of this loop: step s is submitted (ids uploaded on the copy stream behind
+            # step s-1) and the metrics of step s-1 are read and logged while s computes.  Logged values, their step numbers
+            # and the checkpoint contents are those of the reference's synchronous loop (a save first drains the pipeline).
+            pending = []                                                         # [(ticket, step number)]
+
+            def retire(upto):
+                nonlocal ep_loss, ep_correct
+                while len(pending) > upto:
+                    tk, st = pending.pop(0)
+                    loss, acc = self.step_metrics(tk)
+                    ep_loss += loss; ep_correct += acc
+                    history.append((st, loss, acc))
+                    if summary:
+                        summary.scalar('loss', loss, st)                         # :933-936
+                        summary.scalar('accuracy', acc, st)
+                    if show_progress_bar and rank == 0 and (st % 10 == 1):
+                        print('\r- loss: {:.4f} - accuracy: {:.4f}'.format(loss, acc), end='', flush=True)   # :939
+
             for x, y in dataset:                                                 # :914
-                loss, acc = self.train_step(x, y, learning_rate)
-                ep_loss += loss; ep_correct += acc; ep_n += 1
-                history.append((step, loss, acc))
-                if summary:
-                    summary.scalar('loss', loss, step)                           # :933-936
-                    summary.scalar('accuracy', acc, step)
-                if show_progress_bar and rank == 0 and (ep_n % 10 == 1):
-                    print('\r- loss: {:.4f} - accuracy: {:.4f}'.format(loss, acc), end='', flush=True)   # :939
+                pending.append((self.train_step_async(x, y, learning_rate), step))
+                ep_n += 1
+                retire(1)
                 if save_frequency_mode == ModelSaveFrequencyMode.GLOBAL_STEP and step % save_frequency == 0:
+                    retire(0)
                     path = save()                                                # :941-943
                     if path and show_progress_bar:
                         print('\nSaved checkpoint for step {} at {}.'.format(step, path))
                 step += 1                                                        # :945
-                if max_steps is not None and len(history) >= max_steps:
+                if max_steps is not None and len(history) + len(pending) >= max_steps:
                     done = True
                     break
+            retire(0)
             if ep_n == 0:
                 logging.error('The dataset yielded no batches.')
                 break

@@ -79,6 +79,9 @@ void* cmp_ctx_stream(cmp_ctx* ctx);
 int cmp_dp_unique_id(void* id128);                                   /* rank 0: fills 128 bytes */
 int cmp_dp_init(cmp_ctx* ctx, int rank, int nranks, const void* id128);
 int cmp_dp_allreduce_test(cmp_ctx* ctx, float* host_inout, int n);    /* sum over ranks, for tests */
+/* While a communicator exists the persistent GEMM kernels launch at most `cus` workgroups (0 = all 256 CUs), leaving the
+ * rest of the chip to the RCCL kernels of the overlapped gradient all-reduce.  Also settable with COMPOSER_DP_GEMM_CUS. */
+int cmp_dp_set_gemm_cus(cmp_ctx* ctx, int cus);
 
 /* ---- model: replaces models.Transformer(...) construction (cli.py:123-132) --------------------- */
 int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_model** out);
@@ -97,13 +100,19 @@ int cmp_adam_iter_set(cmp_model* m, int64_t iterations);
 
 /* ---- training: one iteration of the loop body at transformer.py:914-930 ------------------------
  * x, y: host int32 [B,T].  Forward (training=True) + sparse-CE + backward + (DP all-reduce) + Adam.
- * loss/acc (host, may be NULL) are this rank's batch mean loss and accuracy. */
+ * loss/acc (host, may be NULL) are the batch mean loss and accuracy -- of this rank's shard, or, once cmp_dp_init has
+ * run, the mean over all ranks (one 3-float all-reduce per step; the reference logs one loss per step, :929-939). */
 int cmp_train_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, float lr,
                    float* loss, float* acc);
 /* Device-resident variant: x_dev/y_dev int32 [B,T] already in HBM; loss/acc are fetched later with
  * cmp_train_metrics (no host sync in the step itself). */
 int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, float lr);
 int cmp_train_metrics(cmp_model* m, float* loss, float* acc);        /* syncs; last step's values */
+/* Pipelined host-buffer step for the train loop (transformer.py:914-946): x/y are copied to pinned staging and uploaded on a
+ * copy stream while earlier steps compute; returns at once with a ticket.  cmp_train_metrics_wait blocks until THAT step has
+ * finished and returns its loss/accuracy.  At most 3 steps are in flight (a 4th submit waits for the oldest). */
+int cmp_train_step_async(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, float lr, int64_t* ticket);
+int cmp_train_metrics_wait(cmp_model* m, int64_t ticket, float* loss, float* acc);
 /* forward+backward only (no all-reduce, no Adam): gradients readable with cmp_param_get(kind=3) */
 int cmp_loss_and_grads(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T,
                        float* loss, float* acc);
@@ -115,8 +124,16 @@ int cmp_eval_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T
 /* ---- inference forward: Transformer.call(inputs, training=False) (transformer.py:696-833) -------
  * logits_out: host fp32 [B,T,V]. */
 int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logits_out);
+/* The general form, Transformer.call(inputs, past=presents, training=...) (transformer.py:696-833):
+ *   past_len > 0: `past` points to L host tensors fp32 [2, B, H, past_len, D] (an earlier call's presents, :735-765); the T
+ *   ids of x are the tokens at positions past_len .. past_len+T-1 (the reference passes the last one, :735-737), their keys
+ *   and values are appended to `past` (:423-426) and logits_out is [B,T,V]; cmp_present_get then takes T' = past_len + T.
+ *   training != 0: dropout active (transformer.py:916-917 calls self(x, training=True)), masks from the model's seed and
+ *   optimizer iteration like a train step's.  Not together with past. */
+int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
+                float* logits_out);
 /* presents[layer] of the LAST forward pass (Transformer.call's second result, transformer.py:797-806, 820-821):
- * host fp32 [2, B, H, T, D] = stack([key, value]) after split_heads.  B, T must be that pass's shape. */
+ * host fp32 [2, B, H, T, D] = stack([key, value]) after split_heads.  B, T must be that pass's shape (T = past + new). */
 int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out);
 
 /* ---- decode: the loop of cli.py:659-676 -------------------------------------------------------

@@ -80,13 +80,13 @@ def _mix32(x):
     return x
 
 
-def dropout_keep_rows(seed, stream, nrows, ncols, p):
+def dropout_keep_rows(seed, stream, nrows, ncols, p, row0=0):
     """Mask [nrows, ncols] (csrc/common.h: attn_row_hash / attn_elem_hash; apply_drop): one full hash per row; the 4
     columns of a group share the xor base and differ by a 24-bit multiplier:
         keep[r, c] = (((rowhash(r) ^ ((c >> 2) * 0x9E3779B1)) & 0xFFFFFF) * C24[c & 3]) mod 2^32 >= p * 2^32.
     Used by every dropout site: rows are tokens (b*T + t) and columns features for the embedding / c_proj / MLP
     outputs; rows are (batch*head, query) and columns keys for the attention probabilities."""
-    rows = np.arange(nrows, dtype=np.uint64)
+    rows = np.arange(row0, row0 + nrows, dtype=np.uint64)        # row0: a window of a larger mask (full-size tests)
     rowh = _mix32(_mix32(rows ^ np.uint64(seed & 0xFFFFFFFF)) ^ np.uint64(stream & 0xFFFFFFFF))
     cols = np.arange(ncols, dtype=np.uint64)
     cq = np.array([0xEBCA6B, 0xB2AE35, 0xD4EB2F, 0x5667B1], dtype=np.uint64)       # 24-bit multipliers

@@ -333,6 +333,47 @@ def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
         assert rel_err(dqkv[:, sl], ref[:, sl]) < tol * 2, name
 
 
+@pytest.mark.parametrize("dtype,T,p", [(BF16, 1024, 0.0), (BF16, 1024, 0.1), (BF16, 2048, 0.0), (BF16, 2048, 0.1), (FP32, 1024, 0.1)])
+def test_attention_full_length_many_groups(lib, dtype, T, p):
+    """BASELINE shapes (seq 1024 / 2048, D = 64) with B*H = 64 (batch, head) groups: the balanced q-block pairing, the XCD
+    re-deal of workgroups and the 64-key fused softmax step run with >= 8 query blocks per group.  The whole grid runs on the
+    GPU; the float64 reference is computed for five (batch, head) groups (first, last and three in between), each of them
+    checked in full: o, lse, dq, dk, dv."""
+    B, H, D = 8, 8, 64
+    E = H * D
+    g = torch.Generator().manual_seed(T + int(p * 100) + dtype)
+    qkv = dev(torch.randn(B * T, 3 * E, generator=g), dtype)
+    do = dev(torch.randn(B * T, E, generator=g), dtype)
+    o = torch.zeros(B * T, E, device="cuda", dtype=tdt(dtype))
+    lse = torch.zeros(B * H * T, device="cuda")
+    ck(lib, lib.cmp_k_attn_fwd(stream(), P(qkv), P(o), P(lse), B, T, H, D, 1, dtype, p, 77, 9))
+    dqkv = torch.zeros(B * T, 3 * E, device="cuda", dtype=tdt(dtype))
+    delta = torch.zeros(B * H * T, device="cuda")
+    ck(lib, lib.cmp_k_attn_bwd(stream(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, dtype, p, 77, 9))
+    torch.cuda.synchronize()
+    qh = qkv.double().cpu().reshape(B, T, 3, H, D)
+    oh = o.double().cpu().reshape(B, T, H, D)
+    dh = do.double().cpu().reshape(B, T, H, D)
+    gh = dqkv.double().cpu().reshape(B, T, 3, H, D)
+    lh = lse.cpu().reshape(B, H, T)
+    tol = TOL[dtype] * (3 if dtype == BF16 else 1)
+    tri = torch.tril(torch.ones(T, T, dtype=torch.float64))
+    for b, h in ((0, 0), (1, 5), (3, 2), (6, 7), (7, 7)):
+        x = qh[b, :, :, h, :].clone().requires_grad_(True)          # [T, 3, D]
+        w = (x[:, 0] @ x[:, 1].T) * (1.0 / math.sqrt(D))
+        w = w * tri - 1e4 * (1 - tri)
+        pr = torch.softmax(w, -1)
+        if p > 0:
+            keep = O.dropout_keep_rows(77, 9, T, T, p, row0=(b * H + h) * T)
+            pr = pr * torch.tensor(keep / (1 - p))
+        oref = pr @ x[:, 2]
+        oref.backward(dh[b, :, h, :])
+        assert rel_err(oh[b, :, h, :], oref.detach()) < tol, (b, h)
+        assert rel_err(lh[b, h], torch.logsumexp(w, -1).detach()) < (1e-5 if dtype == FP32 else 2e-2), (b, h)
+        for j, name in enumerate(("dq", "dk", "dv")):
+            assert rel_err(gh[b, :, j, h, :], x.grad[:, j]) < tol * 2, (b, h, name)
+
+
 def test_attention_forced_rescale(lib):
     """Online-softmax rescale branch: a key far down the sequence dominates a query row (rule: force the branch)."""
     B, T, H, D = 1, 192, 1, 64

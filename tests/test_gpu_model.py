@@ -180,14 +180,166 @@ def test_evaluate_matches_oracle_loss():
 
 
 def test_single_rank_communicator_does_not_change_the_step():
-    """RCCL path with nranks=1: same call sequence as the 8-GPU job (buckets, side stream, 1/N scale)."""
+    """RCCL path with a 1-rank communicator.  model.hip runs the data-parallel sequence whenever a communicator exists
+    (bucket event -> side-stream ncclAllReduce per decoder block, the 3-float metrics all-reduce, Adam behind the last
+    bucket with the 1/N scale), so this executes the product DP code of the 8-GPU job on one GPU; results must not move."""
     g, cfg, params = load_golden("gA")
     from composer_amd.transformer import Transformer
     m = make_model(cfg, params, "fp32")
     m.init_data_parallel(0, 1, Transformer.new_unique_id())
+    assert m.all_reduce_sum([1.5, -2.0, 3.25]).tolist() == [1.5, -2.0, 3.25]          # cmp_dp_allreduce_test
     for s in range(3):
-        loss, _ = m.train_step(g["x"][s], g["y"][s], float(g["lr"]))
+        loss, acc = m.train_step(g["x"][s], g["y"][s], float(g["lr"]))
         assert abs(loss - g["losses"][s]) <= 1e-4 * abs(g["losses"][s])
+        assert abs(acc - g["accs"][s]) < 1e-6                                           # metrics went through the all-reduce
+    for n in m.parameter_names:
+        if "param3:" + n in g.files:
+            assert np.abs(m.get_parameter(n) - g["param3:" + n]).max() <= 2e-5, n
+    m.close()
+
+
+def test_two_shard_gradient_mean_equals_global_batch_on_the_hip_path():
+    """Data-parallel equivalence on the product kernels: the mean of the HIP gradients of rows [0,B) and
+    [B,2B) -- what the RCCL sum + the 1/N scale in the Adam kernel produce -- equals the HIP gradient of the 2B global batch."""
+    from composer_amd import _lib
+    V, E, H, L, W, T, B = 390, 64, 4, 2, 40, 40, 3
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=31).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(5), V, 2 * B, T)
+    m = make_model((V, E, H, L, W, T, 2 * B), params, "fp32")
+    grads = []
+    for sl in (slice(0, B), slice(B, 2 * B), slice(0, 2 * B)):
+        loss, _ = m.loss_and_grads(x[sl], y[sl])
+        grads.append((loss, {n: m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64) for n in m.parameter_names}))
+    assert abs(0.5 * (grads[0][0] + grads[1][0]) - grads[2][0]) < 1e-5
+    for n in m.parameter_names:
+        mean = 0.5 * (grads[0][1][n] + grads[1][1][n])
+        assert np.abs(mean - grads[2][1][n]).max() <= 2e-5 * np.abs(grads[2][1][n]).max() + 1e-10, n
+    m.close()
+
+
+def test_gemm_cu_cap_under_a_communicator_keeps_the_results():
+    """cmp_dp_set_gemm_cus: with a communicator the persistent GEMM kernels launch on a subset of the CUs (leaving the rest to
+    RCCL).  The tile arithmetic does not depend on the grid, so three bf16 steps at a size that takes the persistent kernels
+    give the same losses with 256, 200 and 37 workgroups."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W, T, B = 390, 256, 4, 2, 256, 256, 8
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=2).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(9), V, B, T)
+    curves = []
+    for cus in (None, 200, 37):
+        m = make_model((V, E, H, L, W, T, B), params, "bf16")
+        m.init_data_parallel(0, 1, Transformer.new_unique_id(), gemm_cus=cus)
+        curves.append([m.train_step(x, y, 1e-3)[0] for _ in range(3)])
+        m.close()
+    assert np.allclose(curves[0], curves[1], rtol=2e-3) and np.allclose(curves[0], curves[2], rtol=2e-3), curves
+    assert curves[0][-1] < curves[0][0]
+
+
+def test_call_with_past_matches_oracle():
+    """Transformer.call(inputs, past=presents) (transformer.py:735-765, 423-426): feeding the presents of an earlier call back
+    from the host reproduces the oracle's forward(past=...) logits, step by step, and the returned presents grow by one
+    position per call.  Both accepted forms of `past`: the lazy Presents object and a list of arrays."""
+    g, cfg, params = load_golden("gB")
+    V, E, H, L, W, T, B = cfg
+    m = make_model(cfg, params, "fp32")
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), {k: v.astype(np.float64) for k, v in params.items()})
+    x = g["x"][0][:, :12]
+    lg, pres = m(x[:, :7])
+    olg, opast, _ = orc.forward(x[:, :7])
+    assert np.abs(lg - olg).max() <= 1e-4
+    for t in range(7, 12):
+        past = pres if t % 2 else [np.array(p) for p in pres]
+        lg, pres = m(x[:, :t + 1], past=past)                      # only the last token is used (:735-737)
+        olg, opast, _ = orc.forward(x[:, t:t + 1], past=opast)
+        assert lg.shape == (B, 1, V)
+        assert np.abs(lg - olg).max() <= 1e-4, t
+        assert len(pres) == L and pres[0].shape == (2, B, H, t + 1, E // H)
+        assert np.abs(pres[L - 1] - opast[L - 1]).max() <= 2e-5 * max(1.0, np.abs(opast[L - 1]).max())
+    # ... and equals the last row of one full forward pass
+    full, _ = m(x)
+    assert np.abs(full[:, -1] - lg[:, 0]).max() <= 1e-4
+    with pytest.raises(IndexError):
+        m(x[:, :1], past=[np.zeros((2, B, H, W, E // H), np.float32)] * L)      # position W is outside the wpe table
+    m.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_call_training_true_applies_the_train_step_dropout(dtype, tol):
+    """self(x, training=True) (transformer.py:916-917): logits with dropout on, masks = the shared counter hash at the current
+    optimizer iteration, against the oracle's forward(training=True)."""
+    V, E, H, L, W, T, B = 390, 64, 4, 2, 48, 40, 2
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=21, stddev=0.1).items()}
+    x, _ = O.synthetic_batch(np.random.default_rng(8), V, B, T)
+    ocfg = O.Config(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1)
+    orc = O.OracleTransformer(ocfg, params, seed=99)
+    want, _, _ = orc.forward(x, training=True, step=0)
+    m = make_model((V, E, H, L, W, T, B), params, dtype, p_attn=0.1, p_resid=0.1, seed=99)
+    got, _ = m(x, training=True)
+    assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+    off, _ = m(x)
+    assert np.abs(off - want).max() > 10 * tol          # and it differs from the inference pass
+    m.close()
+
+
+def test_ids_out_of_range_are_rejected_everywhere():
+    """Every entry point refuses token ids outside [0, V): host paths before anything is launched, the device-pointer train
+    step by a device-side clamp + count that cmp_train_metrics reports (evaluate / loss_and_grads / step_device)."""
+    import torch
+    from composer_amd import _lib
+    g, cfg, params = load_golden("gA")
+    V, E, H, L, W, T, B = cfg
+    m = make_model(cfg, params, "fp32")
+    x, y = g["x"][0].copy(), g["y"][0].copy()
+    bad = x.copy(); bad[0, 3] = V
+    neg = y.copy(); neg[1, 0] = -1
+    for fn in (lambda: m(bad), lambda: m.loss_and_grads(bad, y), lambda: m.loss_and_grads(x, neg), lambda: m.evaluate([(x, neg)]),
+               lambda: m.train_step(bad, y), lambda: m.train_step_async(x, neg)):
+        with pytest.raises(ValueError):
+            fn()
+    xd = torch.from_numpy(bad.astype(np.int32)).cuda(); yd = torch.from_numpy(y.astype(np.int32)).cuda()
+    m.train_step_device(xd.data_ptr(), yd.data_ptr(), B, T, 1e-3)
+    with pytest.raises(_lib.HipLibraryError, match="outside"):
+        m.last_metrics()
+    m.train_step_device(torch.from_numpy(x.astype(np.int32)).cuda().data_ptr(), yd.data_ptr(), B, T, 1e-3)
+    assert np.isfinite(m.last_metrics()[0])
+    m.close()
+
+
+def test_pipelined_train_loop_logs_the_synchronous_values(tmp_path):
+    """Transformer.train submits step s+1 before it reads step s (cmp_train_step_async / cmp_train_metrics_wait): the logged
+    (step, loss, accuracy) triples and the saved checkpoints equal those of one synchronous train_step per batch."""
+    g, cfg, params = load_golden("gA")
+    ds = [(g["x"][i], g["y"][i]) for i in range(6)]
+    m = make_model(cfg, params, "fp32")
+    hist = m.train(ds, (cfg[6], cfg[5]), tmp_path / "run", epochs=2, learning_rate=float(g["lr"]),
+                   save_frequency_mode="global_step", save_frequency=4, max_checkpoints=3, show_progress_bar=False)
+    ref = make_model(cfg, params, "fp32")
+    want = [ref.train_step(x, y, float(g["lr"])) for x, y in ds]
+    assert [h[0] for h in hist] == [1, 2, 3, 4, 5, 6]
+    assert np.allclose([h[1] for h in hist], [w[0] for w in want], rtol=1e-5)
+    assert np.allclose([h[1] for h in hist], g["losses"][:6], rtol=1e-4)
+    sd, meta = __import__("composer_amd.checkpoint", fromlist=["load"]).load(str(tmp_path / "run" / "ckpt-1"))
+    assert int(meta["step"]) == 4 and int(sd["optimizer/iter"]) == 4          # saved after step 4, before step 5 ran
+    ref2 = make_model(cfg, params, "fp32")
+    for x, y in ds[:4]:
+        ref2.train_step(x, y, float(g["lr"]))
+    for n in ref2.parameter_names:
+        assert np.allclose(sd["model/" + n], ref2.get_parameter(n), atol=1e-6), n
+    m.close(); ref.close(); ref2.close()
+
+
+def test_bf16_embedding_size_not_a_multiple_of_32():
+    """E = 48 (H = 3, D = 16) in bf16 mode -- the transposed weight copy has partial 32x32 tiles."""
+    V, E, H, L, W, T, B = 390, 48, 3, 2, 32, 24, 2
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=13, stddev=0.1).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(3), V, B, T)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
+    loss, acc, G, logits = orc.loss_and_grads(x, y, training=False)
+    m = make_model((V, E, H, L, W, T, B), params, "bf16")
+    got, _ = m(x)
+    assert np.abs(got - logits).max() <= 4e-2 * np.abs(logits).max()
+    l2, _ = m.loss_and_grads(x, y)
+    assert abs(l2 - loss) <= 2e-2 * loss
     m.close()
 
 
@@ -248,29 +400,106 @@ def test_checkpoint_roundtrip_resumes_bit_identically(tmp_path):
     m.close(); m2.close()
 
 
-# ----------------------------------------------------------------------------- full-size properties (BASELINE configs)
+# ----------------------------------------------------------------------------- full-size configurations (BASELINE configs 2 and 4)
+def _full_size(E, H, L, T, B, dtype, p=0.0, seed=0):
+    from composer_amd.transformer import Transformer
+    m = Transformer(390, E, T, L, H, attention_dropout_rate=p, residual_dropout_rate=p, dtype=dtype, seed=seed, max_batch=B, max_seq=T)
+    params = {k: v.astype(np.float32) for k, v in O.init_params(390, E, T, L, seed=0).items()}
+    m.set_weights(params)
+    return m, params
+
+
 def test_full_size_c2_properties():
     """6L/8H/d512, T=1024 (BASELINE config 2) in bf16: size-independent properties -- finite loss near ln(390) at
     init, loss falls when the same batch is repeated, eval(batch) is permutation-equivariant over batch rows."""
-    from composer_amd.transformer import Transformer
     V, E, H, L, W, T, B = 390, 512, 8, 6, 1024, 1024, 4
-    m = Transformer(V, E, W, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="bf16", seed=0,
-                    max_batch=B, max_seq=T)
+    m, params = _full_size(E, H, L, T, B, "bf16")
     rng = np.random.default_rng(1234)
     x, y = O.synthetic_batch(rng, V, B, T)
     l0, _ = m.evaluate([(x, y)])
     assert 5.9 < l0 < 7.2          # tied embeddings favour the CURRENT token, so the initial loss sits above ln(390)
-    # full model width against the oracle on a slice the oracle finishes in seconds (same seeded init on both sides)
-    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=0).items()}
-    m.set_weights(params)
-    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
-    ref, _ = orc.loss_acc(orc.forward(x[:1, :256])[0], y[:1, :256])
-    got, _ = m.evaluate([(x[:1, :256], y[:1, :256])])
-    assert abs(got - ref) <= 1e-2 * ref, (got, ref)
-    l0, _ = m.evaluate([(x, y)])
     perm = np.array([2, 0, 3, 1])
     lp, _ = m.evaluate([(x[perm], y[perm])])
     assert abs(lp - l0) < 1e-3
     losses = [m.train_step(x, y, 1e-3)[0] for _ in range(6)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05, losses
     m.close()
+
+
+def test_full_size_c2_full_length_row_matches_the_oracle():
+    """BASELINE config 2 at FULL length: one T=1024 row (8 query blocks per head, the balanced q-block pairing and the 64-key
+    softmax step all active) against the float64 oracle -- fp32 mode: every logit <= 1e-4; bf16 mode: loss <= 1e-2 relative and
+    every parameter gradient <= 8e-2 of its largest element (the tolerance of the small-shape dropout test)."""
+    from composer_amd import _lib
+    V, E, H, L, W, T = 390, 512, 8, 6, 1024, 1024
+    x, y = O.synthetic_batch(np.random.default_rng(77), V, 1, T)
+    m32, params = _full_size(E, H, L, T, 1, "fp32")
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
+    loss, acc, G, logits = orc.loss_and_grads(x, y, training=False)
+    got, _ = m32(x)
+    assert np.abs(got - logits).max() <= 1e-4, np.abs(got - logits).max()
+    l32, a32 = m32.loss_and_grads(x, y)
+    assert abs(l32 - loss) <= 1e-5 * loss and abs(a32 - acc) < 1e-6
+    for n in m32.parameter_names:
+        gr = m32.get_parameter(n, _lib.KIND_GRAD).astype(np.float64)
+        assert np.abs(gr - G[n]).max() <= 5e-4 * np.abs(G[n]).max() + 1e-10, n
+    m32.close()
+    mb, _ = _full_size(E, H, L, T, 1, "bf16")
+    lb, _ = mb.loss_and_grads(x, y)
+    assert abs(lb - loss) <= 1e-2 * loss, (lb, loss)
+    worst = max(np.abs(mb.get_parameter(n, _lib.KIND_GRAD).astype(np.float64) - G[n]).max() / (np.abs(G[n]).max() + 1e-12)
+                for n in mb.parameter_names)
+    assert worst <= 8e-2, worst
+    mb.close()
+
+
+def test_full_size_c2_dropout_step_matches_the_oracle():
+    """The benchmark's configuration (dropout 0.1) on a full-length row: bf16 training-mode loss and gradients against the
+    oracle drawing the same counter-hash masks."""
+    from composer_amd import _lib
+    V, E, H, L, W, T = 390, 512, 8, 6, 1024, 1024
+    x, y = O.synthetic_batch(np.random.default_rng(78), V, 1, T)
+    mb, params = _full_size(E, H, L, T, 1, "bf16", p=0.1, seed=5)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1), params, seed=5)
+    loss, acc, G, _ = orc.loss_and_grads(x, y, training=True, step=0)
+    lb, _ = mb.loss_and_grads(x, y)
+    assert abs(lb - loss) <= 1e-2 * loss, (lb, loss)
+    worst = max(np.abs(mb.get_parameter(n, _lib.KIND_GRAD).astype(np.float64) - G[n]).max() / (np.abs(G[n]).max() + 1e-12)
+                for n in mb.parameter_names)
+    assert worst <= 8e-2, worst
+    mb.close()
+
+
+def test_full_size_c4_train_and_eval_properties():
+    """BASELINE config 4: 12L/12H/d768, window 2048, bf16.  Four train steps on one batch (finite, loss falls), evaluation is
+    permutation-equivariant over batch rows, and the parameter count is the surveyed one."""
+    V, E, H, L, T, B = 390, 768, 12, 12, 2048, 2
+    m, _ = _full_size(E, H, L, T, B, "bf16")
+    assert sum(int(np.prod(m.parameter_shape(n))) for n in m.parameter_names) == 86928384        # SURVEY section 8
+    x, y = O.synthetic_batch(np.random.default_rng(4), V, B, T)
+    l0, _ = m.evaluate([(x, y)])
+    assert 5.9 < l0 < 7.5
+    lp, _ = m.evaluate([(x[::-1], y[::-1])])
+    assert abs(lp - l0) < 1e-3
+    losses = [m.train_step(x, y, 1e-3)[0] for _ in range(4)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05, losses
+    m.close()
+
+
+def test_full_size_c4_matches_the_oracle():
+    """BASELINE config 4 against the oracle: bf16 loss of one FULL-LENGTH row (T=2048) <= 1e-2 relative; fp32-mode logits at
+    full width and depth on T=512 <= 1e-4 absolute."""
+    V, E, H, L, T = 390, 768, 12, 12, 2048
+    x, y = O.synthetic_batch(np.random.default_rng(41), V, 1, T)
+    mb, params = _full_size(E, H, L, T, 1, "bf16")
+    orc = O.OracleTransformer(O.Config(V, E, T, L, H), params, dtype=np.float32)    # float32: [1,12,2048,2048] scores per layer
+    ref, _ = orc.loss_acc(orc.forward(x)[0].astype(np.float64), y)
+    got, _ = mb.evaluate([(x, y)])
+    assert abs(got - ref) <= 1e-2 * ref, (got, ref)
+    mb.close()
+    m32, _ = _full_size(E, H, L, T, 1, "fp32")
+    orc64 = O.OracleTransformer(O.Config(V, E, T, L, H), params)
+    want, _, _ = orc64.forward(x[:, :512])
+    lg, _ = m32(x[:, :512])
+    assert np.abs(lg - want).max() <= 1e-4, np.abs(lg - want).max()
+    m32.close()
