@@ -40,6 +40,7 @@ struct DecodeState {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int mode = 0;
+    bool v1 = false;            // COMPOSER_DECODE_V1=1: first-generation per-token kernels
     float temperature = 0.f;
     uint64_t seed = 0;
     int produced = 0, returned = 0, cap = 0, pos = 0;
@@ -348,6 +349,370 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict
     for (int e = tid; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)pos * E + e];
 }
 
+
+// =================================================================================================
+// v2 per-token kernels (default).  Same arithmetic, shorter dependent chains inside each kernel:
+//   * reductions by DPP row operations + v_readlane (no ds_bpermute round trips, one workgroup barrier per block reduction)
+//   * the LayerNorm prologue keeps its input in registers (one global read of x instead of three)
+//   * a column can be split over 2 or 4 waves so that the narrow GEMVs (N = E) still fill all 256 CUs
+//   * attention: K cache stored [H][D/4][W][4] so that TWO lanes own a key (no 16-lane shuffle per score), the current
+//     token's k/v are taken from the c_attn output instead of a write -> barrier -> read through the cache, and the V rows
+//     are requested before the softmax so their latency hides under it.
+// COMPOSER_DECODE_V1=1 selects the first-generation kernels above (A/B timing on one box).
+// =================================================================================================
+#define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+#define DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+#define DPP_XOR1 0xB1          // quad_perm(1,0,3,2)
+#define DPP_XOR2 0x4E          // quad_perm(2,3,0,1)
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+__device__ __forceinline__ float rl_f(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+// sum / max of the 64 lanes, same value (and same summation order) in every lane
+__device__ __forceinline__ float wave_sum2(float v) {
+    v += DPP_F(v, DPP_XOR1);
+    v += DPP_F(v, DPP_XOR2);
+    v += DPP_F(v, DPP_HALF_MIRROR);
+    v += DPP_F(v, DPP_MIRROR);
+    return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
+}
+__device__ __forceinline__ float wave_max2(float v) {
+    v = fmaxf(v, DPP_F(v, DPP_XOR1));
+    v = fmaxf(v, DPP_F(v, DPP_XOR2));
+    v = fmaxf(v, DPP_F(v, DPP_HALF_MIRROR));
+    v = fmaxf(v, DPP_F(v, DPP_MIRROR));
+    return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+}
+// block (4 waves) reductions: one barrier; red must not be in use by a previous reduction that other waves may still read
+__device__ __forceinline__ float block_sum2(float v, float* red) {
+    v = wave_sum2(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max2(float v, float* red) {
+    v = wave_max2(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+#define GV2_XR 8            // LayerNorm input values per thread held in registers: K <= 256 * GV2_XR
+template <int ACT, int IN>
+__global__ __launch_bounds__(256) void dec_gemv2_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, float eps,
+                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                        const float* __restrict__ resid, float* __restrict__ y,
+                                                        float* __restrict__ u_out, int K, int N, int D, int wpc) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [K] | red[16] | combine weights
+    float* red = xs + K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave -> (column, K part): wpc waves share one column
+    const int cpw = 4 / wpc;                       // columns per workgroup
+    const int n = blockIdx.x * cpw + wave / wpc;
+    const int part = wave % wpc;
+    const int Kp = K / wpc;
+    const float* wr = Wt + (int64_t)min(n, N - 1) * K + part * Kp;
+    f32x4 wv[GV_MAXI];
+#pragma unroll
+    for (int i = 0; i < GV_MAXI; i++) {
+        const int k = (lane + 64 * i) * 4;
+        wv[i] = (k < Kp) ? *reinterpret_cast<const f32x4*>(wr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (IN == 1) {
+        float xr[GV2_XR], gr[GV2_XR], br[GV2_XR];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < GV2_XR; i++) {
+            const int k = tid + 256 * i;
+            xr[i] = k < K ? x[k] : 0.f;
+            gr[i] = k < K ? ln_g[k] : 0.f;
+            br[i] = k < K ? ln_b[k] : 0.f;
+            s += xr[i];
+        }
+        const float mu = block_sum2(s, red) / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < GV2_XR; i++) {
+            const int k = tid + 256 * i;
+            const float dd = k < K ? xr[i] - mu : 0.f;
+            q += dd * dd;
+        }
+        const float var = block_sum2(q, red + 4) / (float)K;
+        const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < GV2_XR; i++) {
+            const int k = tid + 256 * i;
+            if (k < K) {
+                const float v = (xr[i] - mu) * rs * gr[i] + br[i];
+                xs[k] = v;
+                if (u_out && blockIdx.x == 0) u_out[k] = v;
+            }
+        }
+    } else if (IN == 2) {
+        float* cw = red + 16;                             // [H * ATT_SPLITS]
+        const int H = K / D;
+        for (int t = tid; t < H * ATT_SPLITS; t += 256) {
+            const int h = t / ATT_SPLITS;
+            const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
+            float mv[ATT_SPLITS], sv[ATT_SPLITS];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sI = 0; sI < ATT_SPLITS; sI++) { mv[sI] = p[sI * (D + 2) + D]; sv[sI] = p[sI * (D + 2) + D + 1]; mx = fmaxf(mx, mv[sI]); }
+            float den = 0.f;
+#pragma unroll
+            for (int sI = 0; sI < ATT_SPLITS; sI++) den += expf(mv[sI] - mx) * sv[sI];
+            cw[t] = expf(mv[t % ATT_SPLITS] - mx) / den;                    // exp(-inf) = 0 for empty splits
+        }
+        // the partial outputs are requested before the barrier that publishes the weights
+        float pv[2][ATT_SPLITS];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int k = tid + 256 * i;
+            const int h = k < K ? k / D : 0, dd = k < K ? k % D : 0;
+            const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
+#pragma unroll
+            for (int sI = 0; sI < ATT_SPLITS; sI++) pv[i][sI] = p[sI * (D + 2) + dd];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int k = tid + 256 * i;
+            if (k < K) {
+                const int h = k / D;
+                float num = 0.f;
+#pragma unroll
+                for (int sI = 0; sI < ATT_SPLITS; sI++) num += cw[h * ATT_SPLITS + sI] * pv[i][sI];
+                xs[k] = num;
+            }
+        }
+        for (int k = tid + 512; k < K; k += 256) {                          // K > 512 (wider models): the plain loop
+            const int h = k / D, dd = k % D;
+            const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
+            float num = 0.f;
+#pragma unroll
+            for (int sI = 0; sI < ATT_SPLITS; sI++) num += cw[h * ATT_SPLITS + sI] * p[sI * (D + 2) + dd];
+            xs[k] = num;
+        }
+    } else {
+        for (int k = tid * 4; k < K; k += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + k);
+            *reinterpret_cast<f32x4*>(xs + k) = v;
+            if (u_out && blockIdx.x == 0) *reinterpret_cast<f32x4*>(u_out + k) = v;
+        }
+    }
+    __syncthreads();
+    float acc = 0.f;
+    const float* xp = xs + part * Kp;
+#pragma unroll
+    for (int i = 0; i < GV_MAXI; i++) {
+        const int k = (lane + 64 * i) * 4;
+        if (k < Kp) {
+            f32x4 xv = *reinterpret_cast<const f32x4*>(xp + k);
+            acc += xv[0] * wv[i][0] + xv[1] * wv[i][1] + xv[2] * wv[i][2] + xv[3] * wv[i][3];
+        }
+    }
+    float v = wave_sum2(acc);
+    if (wpc > 1) {                                   // fixed-order sum of the column's K parts
+        float* r2 = red + 8;
+        if (lane == 0) r2[wave] = v;
+        __syncthreads();
+        if (part != 0) return;
+        v = r2[wave];
+        for (int pI = 1; pI < wpc; pI++) v += r2[wave + pI];
+    }
+    if (n >= N) return;
+    if (lane == 0) {
+        if (bias) v += bias[n];
+        if (ACT == 1) v = gelu_f<true>(v);
+        if (resid) v += resid[n];
+        y[n] = v;
+    }
+}
+
+// Split-key single-query attention, grid (H, ATT_SPLITS).  K cache layout [H][D/4][W][4] (chunk-major): the two lanes that
+// own key j read chunk c of it at ((h*D/4 + c)*W + j)*4 -- 32 consecutive keys per half wave are one contiguous 512 bytes.
+// V cache [H][W][D].  The current token (key == pos) is read from the c_attn output and appended to both caches by the
+// workgroup whose key range holds it.
+__host__ __device__ static inline int attn2_cap(int W) { return ((W + ATT_SPLITS - 1) / ATT_SPLITS + 4 + 3) & ~3; }   // score slots (multiple of 4)
+template <int D>
+__global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict__ qkv, float* __restrict__ kcT,
+                                                        float* __restrict__ vc, float* __restrict__ part,
+                                                        const DecState* __restrict__ st, int E, int W, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // scores[cap] | red[16] | opart[groups][D]
+    constexpr int CH = D / 4;                       // 16-byte chunks per row
+    constexpr int CPL = CH / 2;                     // chunks per lane of a key pair
+    constexpr int GROUPS = 256 / CH;                // V phase: key groups
+    constexpr int VMAX = 8;
+    const int cap = attn2_cap(W);
+    float* sc = sm;
+    float* red = sm + cap;
+    float* opart = red + 16;
+    const int tid = threadIdx.x, h = blockIdx.x, sp = blockIdx.y;
+    const int pos = st->pos;
+    const int chunk = ((pos + 1 + ATT_SPLITS - 1) / ATT_SPLITS + 3) & ~3;
+    const int j0 = sp * chunk, j1 = min(pos + 1, j0 + chunk);
+    const int nk = j1 - j0;
+    float* out = part + ((size_t)h * ATT_SPLITS + sp) * (D + 2);
+    if (nk <= 0) {
+        if (tid < D) out[tid] = 0.f;
+        if (tid == 0) { out[D] = -INFINITY; out[D + 1] = 0.f; }
+        return;
+    }
+    const float* qh = qkv + h * D;
+    const float* kcur = qkv + E + h * D;
+    const float* vcur = qkv + 2 * E + h * D;
+    float* kh = kcT + (int64_t)h * CH * W * 4;
+    float* vh = vc + (int64_t)h * W * D;
+    // ---- scores
+    const int pair = tid >> 1, half = tid & 1;
+    f32x4 qv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) qv[c] = *reinterpret_cast<const f32x4*>(qh + (half * CPL + c) * 4);
+    // V phase mapping and its first pass of loads (no dependence on the scores)
+    const int g = tid / CH, vcI = tid % CH;
+    f32x4 vv[VMAX];
+#pragma unroll
+    for (int u = 0; u < VMAX; u++) {
+        const int j = g + u * GROUPS;
+        const int key = j0 + j;
+        const float* src = (key == pos) ? vcur + vcI * 4 : vh + (int64_t)key * D + vcI * 4;
+        vv[u] = (j < nk) ? *reinterpret_cast<const f32x4*>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float mx = -INFINITY;
+    for (int jb = 0; jb < nk; jb += 128) {
+        const int j = jb + pair;
+        const int key = j0 + j;
+        const bool valid = j < nk;
+        const bool cur = key == pos;
+        f32x4 kv[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int cc = half * CPL + c;
+            const float* src = cur ? kcur + cc * 4 : kh + ((int64_t)cc * W + key) * 4;
+            kv[c] = valid ? *reinterpret_cast<const f32x4*>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) a += qv[c][0] * kv[c][0] + qv[c][1] * kv[c][1] + qv[c][2] * kv[c][2] + qv[c][3] * kv[c][3];
+        a += DPP_F(a, DPP_XOR1);
+        a *= scale;
+        if (valid) {
+            if (half == 0) sc[j] = a;
+            mx = fmaxf(mx, a);
+        }
+    }
+    // append the current token to the caches (read by later tokens only)
+    if (pos >= j0 && pos < j1 && tid < D) {
+        kh[((int64_t)(tid >> 2) * W + pos) * 4 + (tid & 3)] = kcur[tid];
+        vh[(int64_t)pos * D + tid] = vcur[tid];
+    }
+    mx = block_max2(mx, red);            // the barrier inside also publishes sc[]
+    float s = 0.f;
+    for (int j = tid; j < nk; j += 256) {
+        const float p = expf(sc[j] - mx);
+        sc[j] = p;
+        s += p;
+    }
+    s = block_sum2(s, red + 4);          // barrier: p values visible
+    // ---- P.V
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < VMAX; u++) {
+        const int j = g + u * GROUPS;
+        if (j < nk) { const float p = sc[j]; o += vv[u] * p; }
+    }
+    for (int jb = VMAX * GROUPS; jb < nk; jb += VMAX * GROUPS) {           // long key ranges: further passes
+#pragma unroll
+        for (int u = 0; u < VMAX; u++) {
+            const int j = jb + g + u * GROUPS;
+            const int key = j0 + j;
+            const float* src = (key == pos) ? vcur + vcI * 4 : vh + (int64_t)key * D + vcI * 4;
+            vv[u] = (j < nk) ? *reinterpret_cast<const f32x4*>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < VMAX; u++) {
+            const int j = jb + g + u * GROUPS;
+            if (j < nk) { const float p = sc[j]; o += vv[u] * p; }
+        }
+    }
+    *reinterpret_cast<f32x4*>(opart + g * D + vcI * 4) = o;
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < GROUPS; gg++) t += opart[gg * D + tid];
+        out[tid] = t;
+    }
+    if (tid == 0) { out[D] = mx; out[D + 1] = s; }
+}
+
+// K rows of the prompt into the chunk-major cache of dec_attn2_kernel
+template <typename T>
+__global__ void cache_fill2_kernel(const T* __restrict__ qkv, float* __restrict__ kcT, float* __restrict__ vc, int P, int E,
+                                   int H, int D, int W) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * E) return;
+    int t = i / E, e = i % E, h = e / D, d = e % D;
+    kcT[(((int64_t)h * (D / 4) + (d >> 2)) * W + t) * 4 + (d & 3)] = to_f32<T>(qkv[(int64_t)t * 3 * E + E + e]);
+    vc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + 2 * E + e]);
+}
+
+// next id from logits[V] (argmax with lowest index on ties, or Gumbel-max), then the next input embedding
+__global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restrict__ logits, int ldz_row_off, int V,
+                                                          float temperature, unsigned seed, DecState* __restrict__ st,
+                                                          int32_t* __restrict__ ids, const float* __restrict__ wte,
+                                                          const float* __restrict__ wpe, float* __restrict__ x, int E,
+                                                          int first) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* z = logits + ldz_row_off;
+    const unsigned ctr = st->rng;
+    const int pos0 = st->pos, adv = st->advance, nprod = st->produced, capI = st->cap, Wn = st->W;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        float v = z[c];
+        if (temperature > 0.f) {
+            unsigned hsh = drop_hash(seed, 0xC0FFEEu + ctr, (uint64_t)c);
+            float u = ((float)(hsh >> 9) + 0.5f) * (1.0f / 8388608.0f);       // 23 bits + 0.5: exact, strictly inside (0,1)
+            v = v / temperature - logf(-logf(u));
+        }
+        if (v > best) { best = v; arg = c; }
+    }
+#define ARGMAX_STEP(ctrl)                                                        \
+    {                                                                            \
+        const float ov = DPP_F(best, ctrl);                                      \
+        const int oi = DPP_I(arg, ctrl);                                         \
+        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }      \
+    }
+    ARGMAX_STEP(DPP_XOR1) ARGMAX_STEP(DPP_XOR2) ARGMAX_STEP(DPP_HALF_MIRROR) ARGMAX_STEP(DPP_MIRROR)
+#undef ARGMAX_STEP
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = rl_f(best, r);
+        const int oi = __builtin_amdgcn_readlane(arg, r);
+        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+    }
+    // lane 0 of every wave now holds the wave's winner (rows merged into row 0's lanes)
+    if (lane == 0) { bv[wave] = best; bi[wave] = arg; }
+    __syncthreads();
+    float fb = bv[0];
+    int id = bi[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++)
+        if (bv[w] > fb || (bv[w] == fb && bi[w] < id)) { fb = bv[w]; id = bi[w]; }
+    int pos = first ? pos0 : (adv ? pos0 + 1 : 0);
+    if (tid == 0) {
+        if (nprod < capI) ids[nprod] = id;
+        st->produced = nprod + 1;
+        st->rng = ctr + 1;
+        st->token = id;
+        st->pos = pos;
+    }
+    if (pos >= Wn) pos = Wn - 1;         // host refuses to step past the table; never index outside it
+    for (int e = tid; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)pos * E + e];
+}
+
 // -------------------------------------------------------------------------------------------------
 static int launch_gemv(hipStream_t s, int act, int in_mode, const float* x, const float* g, const float* b, float eps,
                        const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D) {
@@ -362,8 +727,64 @@ static int launch_gemv(hipStream_t s, int act, int in_mode, const float* x, cons
     return CMP_OK;
 }
 
+static int launch_gemv2(hipStream_t s, int act, int in_mode, const float* x, const float* g, const float* b, float eps,
+                        const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D) {
+    // waves per column: the narrow outputs are split over 2 or 4 waves so that >= 256 workgroups exist
+    int wpc = 1;
+    while (wpc < 4 && cdiv(N * wpc, 4) < 256 && K % (8 * wpc) == 0) wpc *= 2;
+    CMP_REQUIRE(K % 4 == 0 && K / wpc <= 256 * GV_MAXI, "decode gemv: K=%d unsupported (max %d)", K, 256 * GV_MAXI);
+    CMP_REQUIRE(in_mode != 1 || K <= 256 * GV2_XR, "decode gemv: LayerNorm width %d unsupported (max %d)", K, 256 * GV2_XR);
+    const int grid = cdiv(N * wpc, 4);
+    size_t smem = (size_t)(K + 16 + (in_mode == 2 ? (K / D) * ATT_SPLITS : 0)) * 4;
+#define GV(A, I) dec_gemv2_kernel<A, I><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D, wpc)
+    if (act == 1) { if (in_mode == 1) GV(1, 1); else if (in_mode == 2) GV(1, 2); else GV(1, 0); }
+    else { if (in_mode == 1) GV(0, 1); else if (in_mode == 2) GV(0, 2); else GV(0, 0); }
+#undef GV
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+static int launch_attn2(hipStream_t s, cmp_model* m, DecodeState* d, const DecLayerW& w, float scale) {
+    const size_t smem = (size_t)(attn2_cap(m->W) + 16 + 1024) * 4;
+    dim3 grid(m->H, ATT_SPLITS);
+    switch (m->D) {
+        case 16: dec_attn2_kernel<16><<<grid, 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
+        case 32: dec_attn2_kernel<32><<<grid, 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
+        case 64: dec_attn2_kernel<64><<<grid, 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
+        default: dec_attn2_kernel<128><<<grid, 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
+    }
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
+    hipStream_t s = m->ctx->stream;
+    const int E = m->E, L = m->L;
+    const bool ln = m->cfg.use_layer_norm != 0;
+    const float eps = m->cfg.ln_eps;
+    const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->D) : 1.0f;
+    for (int i = 0; i < L; i++) {
+        const LayerOff& o = m->lo[i];
+        const DecLayerW& w = d->lw[i];
+        CHECK_RC(launch_gemv2(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
+                              d->qkv, d->u, E, 3 * E, m->D));
+        CHECK_RC(launch_attn2(s, m, d, w, scale));
+        CHECK_RC(launch_gemv2(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, E, E, m->D));
+        CHECK_RC(launch_gemv2(s, 1, ln ? 1 : 0, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
+                              nullptr, E, 4 * E, m->D));
+        CHECK_RC(launch_gemv2(s, 0, 0, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E, m->D));
+    }
+    CHECK_RC(launch_gemv2(s, 0, 1, d->x, m->P + m->off_lnf_g, m->P + m->off_lnf_b, eps, m->P + m->off_wte, nullptr, nullptr,
+                          d->logits, nullptr, E, m->V, m->D));
+    dec_sample2_kernel<<<1, 256, 0, s>>>(d->logits, 0, m->V, d->temperature, (unsigned)d->seed, d->st, d->ids, m->P + m->off_wte,
+                                         m->P + m->off_wpe, d->x, E, 0);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
 // one token: consumes d->x (embedding of st->token at st->pos), produces the next id and the next d->x
 static int enqueue_token_step(cmp_model* m, DecodeState* d) {
+    if (!d->v1) return enqueue_token_step2(m, d);
     hipStream_t s = m->ctx->stream;
     const int E = m->E, L = m->L;
     const bool ln = m->cfg.use_layer_norm != 0;
@@ -402,6 +823,7 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     DecodeState* d = new DecodeState();
     m->dec = d;
     d->mode = mode;
+    { const char* e = getenv("COMPOSER_DECODE_V1"); d->v1 = e && e[0] == '1'; }
     d->temperature = temperature;
     d->seed = seed;
     d->cap = 1 << 16;
@@ -442,10 +864,17 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     if (mode == CMP_DECODE_KV) {
         for (int i = 0; i < L; i++) {
             int grid = cdiv(P * E, 256);
-            if (m->dtype == CMP_BF16)
-                cache_fill_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
-            else
-                cache_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+            if (d->v1) {
+                if (m->dtype == CMP_BF16)
+                    cache_fill_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+                else
+                    cache_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+            } else {
+                if (m->dtype == CMP_BF16)
+                    cache_fill2_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+                else
+                    cache_fill2_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+            }
             KERNEL_CHECK();
         }
     }
@@ -459,8 +888,12 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     h.W = W;
     HIP_CHECK(hipMemcpyAsync(d->st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     // first id from the last prompt row (cli.py:673 `[-1, 0]`)
-    dec_sample_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, temperature, (unsigned)seed, d->st, d->ids,
-                                        m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
+    if (d->v1)
+        dec_sample_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, temperature, (unsigned)seed, d->st, d->ids,
+                                            m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
+    else
+        dec_sample2_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, temperature, (unsigned)seed, d->st, d->ids,
+                                             m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(s));
     d->produced = 1;
