@@ -121,12 +121,16 @@ def cpu_baseline(cf, seconds_budget=24.0):
     try:
         import torch
         from oracle.torch_restatement import TorchTrainer
-        cores = torch.get_num_threads()
-        for Bc in ((2, 8) if cores >= 32 else (1,)):
+        # torch's CPU ops stop scaling (and then collapse) well below the box's 128-256 hardware threads on this op mix:
+        # measured on the GPU box (tools/cpu_baseline_sweep.py) 16 threads x B=1 is the fastest, 128 threads 10x slower.
+        ncpu = os.cpu_count() or 1
+        for th in sorted({min(16, ncpu), min(32, ncpu)}):
+            torch.set_num_threads(th)
+
             def mk():
                 tr = TorchTrainer(cfg, params)
                 return lambda x, y: tr.train_step(x, y, LR)
-            run("torch-CPU restatement of transformer.py", mk, Bc, seconds_budget * 0.4, cores)
+            run("torch-CPU restatement of transformer.py (%d threads)" % th, mk, 1, seconds_budget * 0.4, th)
     except Exception as e:                              # torch CPU ops unavailable: numpy leg only
         print("cpu_baseline: torch leg failed: %r" % (e,), file=sys.stderr)
     try:
