@@ -59,6 +59,49 @@ __global__ void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __res
     dwpe[(int64_t)(pos0 + t) * E + e] += acc;
 }
 
+// Deterministic form of the dwte scatter-add (COMPOSER_DETERMINISTIC=1): no atomics.  Pass 1, grid (V, SEG): workgroup
+// (v, g) walks the tokens of segment g in order and sums the rows whose id is v into part[v][g][:]; pass 2 adds a row's
+// SEG partials in segment order.  The ids are re-read V times (they stay in L2); every gradient row is read once.
+#define EMB_SEG 64
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_det_part_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dh,
+                                                                 float* __restrict__ part, int ntok, int E, DropCfg drop) {
+    const int v = blockIdx.x, g = blockIdx.y;
+    const int per = cdiv(ntok, EMB_SEG);
+    const int t0 = g * per, t1 = min(ntok, t0 + per);
+    float* out = part + ((size_t)v * EMB_SEG + g) * E;
+    for (int e0 = 0; e0 < E; e0 += 256) {
+        const int e = e0 + threadIdx.x;
+        float acc = 0.f;
+        for (int tok = t0; tok < t1; tok++) {
+            if (ids[tok] != v) continue;                   // uniform over the workgroup
+            if (e < E) acc += apply_drop(drop, (uint32_t)tok, (uint32_t)e, to_f32<T>(dh[(int64_t)tok * E + e]));
+        }
+        if (e < E) out[e] = acc;
+    }
+}
+__global__ void embed_bwd_det_reduce_kernel(const float* __restrict__ part, float* __restrict__ dwte, int V, int E) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)V * E) return;
+    const int v = (int)(i / E), e = (int)(i % E);
+    float a = 0.f;
+    for (int g = 0; g < EMB_SEG; g++) a += part[((size_t)v * EMB_SEG + g) * E + e];
+    dwte[i] += a;
+}
+// dwpe part of embed_bwd_kernel alone (already a fixed-order loop over the batch)
+template <typename T>
+__global__ void embed_bwd_wpe_kernel(const T* __restrict__ dh, float* __restrict__ dwpe, int B, int T_, int E, int pos0, DropCfg drop) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)T_ * E) return;
+    int t = (int)(gid / E), e = (int)(gid % E);
+    float acc = 0.f;
+    for (int b = 0; b < B; b++) {
+        int tok = b * T_ + t;
+        acc += apply_drop(drop, (uint32_t)tok, (uint32_t)e, to_f32<T>(dh[(int64_t)tok * E + e]));
+    }
+    dwpe[(int64_t)(pos0 + t) * E + e] += acc;
+}
+
 // =================================================================================================
 // LayerNorm (Keras non-fused path: biased variance, eps inside rsqrt)   transformer.py:551,563,694
 // one wave per row; a lane owns chunks (lane + 64*i) of 16 bytes.
@@ -427,7 +470,8 @@ __global__ void cast_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __
 // r, r+4, ... (4 loads in flight per lane); cross-wave fold through LDS, one f32 atomic per column per split.
 // =================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out, int rows, int cols) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out, int rows, int cols,
+                                                     float* __restrict__ part) {
     constexpr int VN = Vec16<T>::N;
     __shared__ float sm[4][64 * VN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -457,8 +501,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * VN; i += 256) {
         int c = blockIdx.x * 64 * VN + i;
-        if (c < cols) atomicAdd(out + c, sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i]);
+        const float v = sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i];
+        if (c < cols) {
+            if (part) part[(size_t)blockIdx.y * cols + c] = v;       // deterministic mode: fixed-order fold afterwards
+            else atomicAdd(out + c, v);
+        }
     }
+}
+__global__ void colsum_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int cols) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f;
+    for (int sI = 0; sI < splits; sI++) a += part[(size_t)sI * cols + c];
+    out[c] += a;
 }
 
 // =================================================================================================
@@ -488,9 +543,30 @@ extern "C" int cmp_k_embed_fwd(void* stream, const int32_t* ids, const float* wt
 extern "C" int cmp_k_embed_bwd(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe,
                                int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed,
                                uint32_t rng_stream) {
+    return embed_bwd_run(stream, ids, dh, dwte, dwpe, B, T, E, pos0, dtype, p_drop, seed, rng_stream, 0, nullptr, 0);
+}
+
+// V > 0 with a workspace of V * EMB_SEG * E floats selects the atomic-free (bitwise reproducible) form
+int embed_bwd_run(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe, int B, int T, int E, int pos0,
+                  int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, int V, float* det_ws, size_t det_ws_bytes) {
     hipStream_t s = (hipStream_t)stream;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
     if (B * T == 0) return CMP_OK;
+    if (V > 0 && det_ws) {
+        CMP_REQUIRE((size_t)V * EMB_SEG * E * 4 <= det_ws_bytes, "embed_bwd: deterministic workspace too small");
+        dim3 g1(V, EMB_SEG);
+        const int g2 = (int)cdiv64((int64_t)V * E, 256), g3 = (int)cdiv64((int64_t)T * E, 256);
+        if (dtype == CMP_BF16) {
+            embed_bwd_det_part_kernel<bf16_t><<<g1, 256, 0, s>>>(ids, (const bf16_t*)dh, det_ws, B * T, E, d);
+            embed_bwd_wpe_kernel<bf16_t><<<g3, 256, 0, s>>>((const bf16_t*)dh, dwpe, B, T, E, pos0, d);
+        } else {
+            embed_bwd_det_part_kernel<float><<<g1, 256, 0, s>>>(ids, (const float*)dh, det_ws, B * T, E, d);
+            embed_bwd_wpe_kernel<float><<<g3, 256, 0, s>>>((const float*)dh, dwpe, B, T, E, pos0, d);
+        }
+        embed_bwd_det_reduce_kernel<<<g2, 256, 0, s>>>(det_ws, dwte, V, E);
+        KERNEL_CHECK();
+        return CMP_OK;
+    }
     int grid = (int)cdiv64((int64_t)T * E, 256);
     if (dtype == CMP_BF16)
         embed_bwd_kernel<bf16_t><<<grid, 256, 0, s>>>(ids, (const bf16_t*)dh, dwte, dwpe, B, T, E, pos0, d);
@@ -541,6 +617,14 @@ extern "C" int cmp_k_layernorm_bwd_fused(void* stream, const void* dy, const voi
                                          const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta,
                                          void* ws, int rows, int E, int dtype, void* dmask, float* colsum, float p_drop,
                                          uint64_t seed, uint32_t rng_stream) {
+    return layernorm_bwd_run(stream, dy, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, ws, rows, E, dtype, dmask, colsum, p_drop,
+                             seed, rng_stream, false);
+}
+
+// deterministic: the per-workgroup partials are folded by ONE thread per column in workgroup order (no float atomics)
+int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const void* resid, void* dx, float* dgamma, float* dbeta, void* ws, int rows, int E, int dtype, void* dmask,
+                      float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic) {
     int rc = ln_check(E, dtype);
     if (rc) return rc;
     if (rows == 0) return CMP_OK;
@@ -557,7 +641,7 @@ extern "C" int cmp_k_layernorm_bwd_fused(void* stream, const void* dy, const voi
     else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
 #undef LN_BWD
     KERNEL_CHECK();
-    ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);
+    ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), deterministic ? 1 : std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -607,6 +691,11 @@ int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n) {
 }
 
 extern "C" int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype) {
+    return colsum_run(stream, X, ldx, out, rows, cols, dtype, nullptr, 0);
+}
+
+// det_ws (>= 128 * cols floats): per-split partial sums + a fixed-order fold instead of float atomics
+int colsum_run(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype, float* det_ws, size_t det_ws_bytes) {
     if (rows == 0 || cols == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     const int vn = dtype == CMP_BF16 ? 8 : 4;
@@ -614,10 +703,12 @@ extern "C" int cmp_k_colsum(void* stream, const void* X, int ldx, float* out, in
     const int gx = cdiv(cols, 64 * vn);
     int splits = std::max(1, std::min(std::min(rows / 64, 128), std::max(1, 1024 / gx)));
     dim3 grid(gx, splits);
+    if (det_ws) CMP_REQUIRE((size_t)splits * cols * 4 <= det_ws_bytes, "colsum: deterministic workspace too small");
     if (dtype == CMP_BF16)
-        colsum_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, ldx, out, rows, cols);
+        colsum_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)X, ldx, out, rows, cols, det_ws);
     else
-        colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)X, ldx, out, rows, cols);
+        colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)X, ldx, out, rows, cols, det_ws);
+    if (det_ws) colsum_fold_kernel<<<cdiv(cols, 256), 256, 0, s>>>(det_ws, out, splits, cols);
     KERNEL_CHECK();
     return CMP_OK;
 }

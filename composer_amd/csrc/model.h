@@ -130,6 +130,12 @@ template <typename Tp> static int dev_alloc(cmp_model* m, Tp** p, size_t bytes) 
 }
 
 // elementwise.hip
+int embed_bwd_run(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe, int B, int T, int E, int pos0,
+                  int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, int V, float* det_ws, size_t det_ws_bytes);
+int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const void* resid, void* dx, float* dgamma, float* dbeta, void* ws, int rows, int E, int dtype, void* dmask,
+                      float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic);
+int colsum_run(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype, float* det_ws, size_t det_ws_bytes);
 int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics);
 int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n);
 // model.hip

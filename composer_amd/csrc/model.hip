@@ -391,8 +391,9 @@ int ensure_workspace(cmp_model* m, int B, int T) {
     CHECK_RC(dev_alloc(m, &m->dmask, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->dfc, (size_t)M * 4 * E * es));
     CHECK_RC(dev_alloc(m, &m->dqkv, (size_t)M * 3 * E * es));
-    {   // COMPOSER_DETERMINISTIC=1: split-K wgrads write per-split slabs and reduce them in a fixed order instead of
-        // f32 atomics (bitwise reproducible steps; measured ~7 % slower at C2)
+    {   // COMPOSER_DETERMINISTIC=1: no float atomics anywhere in the step -- split-K wgrads write per-split slabs and fold them
+        // in a fixed order, the bias-gradient column sums and the LayerNorm parameter partials are folded by one thread per
+        // column, the embedding scatter-add becomes a segmented gather.  Bitwise reproducible steps.
         const char* det = getenv("COMPOSER_DETERMINISTIC");
         if (det && det[0] == '1') {
             m->slab_bytes = (int64_t)64 * E * E * 4 + (int64_t)64 * m->V * E * 4;
@@ -455,16 +456,34 @@ static int refresh_transposed_weights(cmp_model* m) {
 // -------------------------------------------------------------------------------------------------
 // forward: Transformer.call (transformer.py:696-833) with past=None
 // -------------------------------------------------------------------------------------------------
+// column sums with per-split partials folded in a fixed order (deterministic mode; the slab is the scratch space)
+static int colsum_det(cmp_model* m, const void* X, int ldx, float* out, int rows, int cols) {
+    return colsum_run(m->ctx->stream, X, ldx, out, rows, cols, m->dtype, (float*)m->slab, (size_t)m->slab_bytes);
+}
+static int colsum_any(cmp_model* m, const void* X, int ldx, float* out, int rows, int cols) {
+    if (m->slab) return colsum_det(m, X, ldx, out, rows, cols);
+    return cmp_k_colsum(m->ctx->stream, X, ldx, out, rows, cols, m->dtype);
+}
+static int ln_bwd(cmp_model* m, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                  const void* resid, void* dx, float* dgamma, float* dbeta, int rows, void* dmask, float* colsum, float p_drop,
+                  uint32_t rng_stream) {
+    return layernorm_bwd_run(m->ctx->stream, dy, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, m->ln_ws, rows, m->E, m->dtype,
+                             dmask, colsum, p_drop, m->cfg.seed, rng_stream, m->slab != nullptr);
+}
+
 static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                 int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
                 int splitk, float p_drop, uint32_t rng_stream, int flags = 0, float* colsum = nullptr) {
+    const bool det = m->slab != nullptr;                               // COMPOSER_DETERMINISTIC=1
     GemmExtra ex;
-    ex.colsum = colsum;
-    if (splitk > 1 && m->slab != nullptr) { ex.slab_ws = (float*)m->slab; ex.slab_bytes = (size_t)m->slab_bytes; }
+    ex.colsum = det ? nullptr : colsum;                                // fused column sums are float atomics
+    if (splitk > 1 && det) { ex.slab_ws = (float*)m->slab; ex.slab_bytes = (size_t)m->slab_bytes; }
     ex.role = m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1);         // forward announces 0; backward: A^T = wgrad, else dgrad
     ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;              // leave CUs to the concurrent all-reduce kernels
-    return gemm_run(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
-                    out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags, ex);
+    CHECK_RC(gemm_run(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
+                      out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags, ex));
+    if (det && colsum) CHECK_RC(colsum_det(m, C, ldc, colsum, M, N));
+    return CMP_OK;
 }
 
 // copies rows (b, s0 + t) of src [*, sT rows per batch, src_ld] to rows (b, d0 + t) of dst, w 16-byte vectors per row
@@ -588,9 +607,9 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                   1, 0.f, 0, CMP_GEMM_KPAD_ZERO));    // dlogits rows are zero-padded to ldz (softmax_xent kernel)
     // dx of every LayerNorm backward below is the gradient of the previous residual branch's dropout output, so the
     // kernel also emits that branch's masked gradient (dmask) and bias gradient (column sums)
-    CHECK_RC(cmp_k_layernorm_bwd_fused(s, m->tmpE, m->xs[m->L], m->P + m->off_lnf_g, m->lnf_mean, m->lnf_rstd, nullptr, m->dx,
-                                       m->G + m->off_lnf_g, m->G + m->off_lnf_b, m->ln_ws, M, E, dt, m->dmask,
-                                       m->G + m->lo[m->L - 1].pr_b, pr, m->cfg.seed, drop_stream(step, m->L - 1, 3)));
+    CHECK_RC(ln_bwd(m, m->tmpE, m->xs[m->L], m->P + m->off_lnf_g, m->lnf_mean, m->lnf_rstd, nullptr, m->dx,
+                    m->G + m->off_lnf_g, m->G + m->off_lnf_b, M, m->dmask, m->G + m->lo[m->L - 1].pr_b, pr,
+                    drop_stream(step, m->L - 1, 3)));
     bool dmo_ready = true;      // dmask / pr_b of the current layer already produced
     if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total));
     for (int i = m->L - 1; i >= 0; i--) {
@@ -604,7 +623,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         }
         CHECK_RC(gemm(m, 1, 0, 4 * E, E, M, a.g, 4 * E, dmo, E, m->G + o.pr_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, 4 * E, E)), 0.f, 0));
-        if (!dmo_ready) CHECK_RC(cmp_k_colsum(s, dmo, E, m->G + o.pr_b, M, E, dt));
+        if (!dmo_ready) CHECK_RC(colsum_any(m, dmo, E, m->G + o.pr_b, M, E));
         CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, dmo, E, m->w(o.pr_w), E, m->dfc, 4 * E, nullptr, 2, a.fc, 4 * E, nullptr, 0, 0, 1,
                       0.f, 0, 0, m->G + o.fc_b));      // dfc = (dmo.Wpr^T) * gelu'(fc); b_fc grad = column sums of dfc
         CHECK_RC(gemm(m, 1, 0, E, 4 * E, M, a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
@@ -612,9 +631,8 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr,
                           0, 0, 1, 0.f, 0));                                       // dn
-            CHECK_RC(cmp_k_layernorm_bwd_fused(s, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr,
-                                               m->G + o.ln2_g, m->G + o.ln2_b, m->ln_ws, M, E, dt, m->dmask, m->G + o.proj_b, pr,
-                                               m->cfg.seed, drop_stream(step, i, 2)));   // dr = dx + LN2'(dn); dao, b_proj grad
+            CHECK_RC(ln_bwd(m, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr, m->G + o.ln2_g, m->G + o.ln2_b, M,
+                            m->dmask, m->G + o.proj_b, pr, drop_stream(step, i, 2)));   // dr = dx + LN2'(dn); dao, b_proj grad
         } else {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->dr, E, nullptr, 0, nullptr, 0, m->dx, E,
                           0, 1, 0.f, 0));                                          // dr = dx + dn
@@ -627,21 +645,22 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         }
         CHECK_RC(gemm(m, 1, 0, E, E, M, a.att, E, dao, E, m->G + o.proj_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       std::max(2, wgrad_splits(M, E, E)), 0.f, 0));
-        if (!ln) CHECK_RC(cmp_k_colsum(s, dao, E, m->G + o.proj_b, M, E, dt));
+        if (!ln) CHECK_RC(colsum_any(m, dao, E, m->G + o.proj_b, M, E));
         CHECK_RC(gemm(m, 0, 1, M, E, E, dao, E, m->w(o.proj_w), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
                       0));                                                         // datt
+        const bool det = m->slab != nullptr;     // the fused bias sums are float atomics: a separate fixed-order pass instead
         CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
-                              dt, pa, m->cfg.seed, drop_stream(step, i, 1), m->G + o.attn_b));   // b_attn grad = column sums of dqkv
+                              dt, pa, m->cfg.seed, drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b));   // b_attn grad = column sums of dqkv
+        if (det) CHECK_RC(colsum_det(m, m->dqkv, 3 * E, m->G + o.attn_b, M, 3 * E));
         CHECK_RC(gemm(m, 1, 0, E, 3 * E, M, a.u, E, m->dqkv, 3 * E, m->G + o.attn_w, 3 * E, nullptr, 0, nullptr, 0, nullptr, 0,
                       1, std::max(2, wgrad_splits(M, E, 3 * E)), 0.f, 0));
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
                           E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T
             // dx_in = LN1'(du): no skip connection around LN1; feeds layer i-1's MLP branch (or the embedding for i = 0)
-            CHECK_RC(cmp_k_layernorm_bwd_fused(s, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx,
-                                               m->G + o.ln1_g, m->G + o.ln1_b, m->ln_ws, M, E, dt, i > 0 ? m->dmask : nullptr,
-                                               i > 0 ? m->G + m->lo[i - 1].pr_b : nullptr, pr, m->cfg.seed,
-                                               drop_stream(step, i > 0 ? i - 1 : 0, 3)));
+            CHECK_RC(ln_bwd(m, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx, m->G + o.ln1_g,
+                            m->G + o.ln1_b, M, i > 0 ? m->dmask : nullptr, i > 0 ? m->G + m->lo[i - 1].pr_b : nullptr, pr,
+                            drop_stream(step, i > 0 ? i - 1 : 0, 3)));
             dmo_ready = true;
         } else {
             dmo_ready = false;
@@ -650,8 +669,8 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         }
         if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end));
     }
-    CHECK_RC(cmp_k_embed_bwd(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->cfg.seed,
-                             drop_stream(step, 0, 0)));
+    CHECK_RC(embed_bwd_run(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->cfg.seed,
+                           drop_stream(step, 0, 0), m->slab ? V : 0, (float*)m->slab, (size_t)m->slab_bytes));
     if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin));
     return CMP_OK;
 }
