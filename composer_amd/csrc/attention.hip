@@ -553,228 +553,6 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
 }
 
 // =================================================================================================
-// forward, 64 query rows per wave (bf16, D <= 64).  grid ((nb2+1)/2, B*H), nb2 = ceil(T/256); wave w owns query rows
-// [qb*256 + 64w, +64) as two 32-row sub-blocks a = 0, 1.
-// Why: in the 32-rows-per-wave kernel above a wave's tile is one serial chain (K fragments -> 8 score MFMAs -> row max ->
-// exponentials -> V fragments -> 8 PV MFMAs) and the SQ counters show the waves parked on LDS waits and the barrier 42 % of
-// the time with the matrix pipe 25 % busy (profiles/r1_08_sq_counters_attention.txt), dropout or not.  With two sub-blocks
-// per wave every K / V fragment read from LDS feeds two MFMAs, there is one barrier per 32 MFMAs instead of per 16, and the
-// program order S(a=0), S(a=1), softmax(a=0), PV(a=0), softmax(a=1), PV(a=1) leaves the matrix pipe working on one
-// sub-block while the vector ALU does the other's softmax.
-// =================================================================================================
-__device__ __forceinline__ bf16x8 ld_kfrag(const bf16_t* Ks, int S, int sub, int s, int lane) {
-    return *reinterpret_cast<const bf16x8*>(Ks + (32 * sub + (lane & 31)) * S + 16 * s + 8 * (lane >> 5));
-}
-__device__ __forceinline__ bf16x8 ld_vfrag(const bf16_t* Vs, int S, int sub, int dt, int step, int lane) {
-    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int col = 32 * dt + 16 * (G & 1) + 4 * p;
-    const int kr = 32 * sub + 16 * step + 4 * (G >> 1) + q;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Vs + kr * S + col));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Vs + (kr + 8) * S + col));
-    bf16x8 a;
-#pragma unroll
-    for (int j = 0; j < 4; j++) { a[j] = lo[j]; a[4 + j] = hi[j]; }
-    return a;
-}
-__device__ __forceinline__ bf16x8 pack_p(const f32x16& x, int step) {
-    bf16x8 b;
-#pragma unroll
-    for (int j = 0; j < 8; j++) b[j] = (bf16_t)x[8 * step + j];
-    return b;
-}
-
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                           float* __restrict__ lse, int Tn, int H, float scale, DropCfg drop) {
-    using T = bf16_t;
-    using G = Geo<T, D>;
-    constexpr int S = G::S, NS = G::NS, DT = G::DT;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Kb = reinterpret_cast<T*>(smem_raw);          // 2 x { K [64][S] | V [64][S] }
-    constexpr int IMG = 64 * S;
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, by;
-    xcd_block(bx, by);
-    const int b = by / H, hd = by % H;
-    const int E = H * D;
-    const int64_t rs = 3 * E;
-    const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
-    const T* kg = qg + E;
-    const T* vg = qg + 2 * E;
-    T* og = o + (int64_t)b * Tn * E + hd * D;
-    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
-    const int nb = cdiv(Tn, 256);
-
-    for (int ph = 0; ph < 2; ph++) {
-        const int qb = pair_block(ph, nb, bx);
-        if (qb < 0) break;
-        const int q0w = qb * 256 + wave * 64;
-        int q[2];
-        bool qvalid[2];
-        bf16x8 qf[2][NS];
-        f32x16 oacc[2][DT];
-        float m[2], lsum[2];
-        uint32_t rowh[2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            q[a] = q0w + 32 * a + (lane & 31);
-            qvalid[a] = q[a] < Tn;
-            load_bfrags<T, D>(qf[a], qg, rs, q[a], qvalid[a], h);
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) oacc[a][dt][r] = 0.f;
-            m[a] = -INFINITY;
-            lsum[a] = 0.f;
-            rowh[a] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q[a]));
-        }
-        const int kv_end = min(Tn, qb * 256 + 256);
-
-        Stager<T, D> sk, sv;
-        sk.load(kg, rs, 0, Tn, tid);
-        sv.load(vg, rs, 0, Tn, tid);
-        sk.store(Kb, tid);
-        sv.store(Kb + IMG, tid);
-        __syncthreads();
-
-        // online-softmax step of sub-block a over a full (unmasked) 64-key tile held in s0 (keys 0-31) and s1 (32-63)
-        auto softmax64 = [&](const int a, f32x16& s0, f32x16& s1, const int kt0) __attribute__((always_inline)) {
-            const float mloc = half_max(fmaxf(max16(s0), max16(s1)));
-            const float mnew = fmaxf(m[a], mloc);
-            if (!__all(mnew == m[a])) {
-                const float alpha = fast_exp2((m[a] - mnew) * c2);
-                lsum[a] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) oacc[a][dt][r] *= alpha;
-                m[a] = mnew;
-            }
-            const float mc = m[a] * c2;
-            f32x2 ps = {0.f, 0.f};
-            ps = exp2_scaled16(s0, c2, -mc, ps);
-            ps = exp2_scaled16(s1, c2, -mc, ps);
-            lsum[a] += ps[0] + ps[1];
-            if constexpr (DROP) {
-                mask16_qlane<true>(s0, rowh[a], kt0, h, drop.thr);
-                mask16_qlane<true>(s1, rowh[a], kt0 + 32, h, drop.thr);
-            }
-        };
-        // the general tile of ONE sub-block (diagonal / sequence-end tiles): the 32-rows-per-wave kernel's logic
-        auto tile_a = [&](const int a, const int kt0, const T* Ks, const T* Vs) __attribute__((always_inline)) {
-            const int q0 = q0w + 32 * a;
-            const bool full64 = (kt0 + 63 <= q0) && (kt0 + 64 <= Tn);      // wave-uniform
-            if (full64) {
-                f32x16 s0, s1;
-#pragma unroll
-                for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
-                s0 = mma_rows<T, D>(Ks, 0, qf[a], lane, s0);
-                s1 = mma_rows<T, D>(Ks, 32, qf[a], lane, s1);
-                softmax64(a, s0, s1, kt0);
-#pragma unroll
-                for (int dt = 0; dt < DT; dt++) {
-                    oacc[a][dt] = mma_acc_b<T, D>(Vs, 0, dt, s0, lane, oacc[a][dt]);
-                    oacc[a][dt] = mma_acc_b<T, D>(Vs, 32, dt, s1, lane, oacc[a][dt]);
-                }
-                return;
-            }
-#pragma unroll
-            for (int sub = 0; sub < 2; sub++) {
-                const int k0 = kt0 + 32 * sub;
-                if (k0 > q0 + 31 || k0 >= Tn) continue;          // wave-uniform: sub-tile entirely masked
-                f32x16 s;
-#pragma unroll
-                for (int r = 0; r < 16; r++) s[r] = 0.f;
-                s = mma_rows<T, D>(Ks, 32 * sub, qf[a], lane, s);
-                const bool edge = (k0 + 31 > q0) || (k0 + 32 > Tn);      // wave-uniform
-                if (edge) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int key = k0 + rho(r, h);
-                        if (key > q[a] || key >= Tn) s[r] = neg_big;       // == -1e4 after scaling (transformer.py:354)
-                    }
-                }
-                const float mloc = half_max(max16(s));
-                const float mnew = fmaxf(m[a], mloc);
-                if (!__all(mnew == m[a])) {
-                    const float alpha = fast_exp2((m[a] - mnew) * c2);
-                    lsum[a] *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) oacc[a][dt][r] *= alpha;
-                    m[a] = mnew;
-                }
-                const float mc = m[a] * c2;
-                const f32x2 ps = exp2_scaled16(s, c2, -mc, f32x2{0.f, 0.f});
-                lsum[a] += ps[0] + ps[1];
-                if constexpr (DROP) mask16_qlane<true>(s, rowh[a], k0, h, drop.thr);
-#pragma unroll
-                for (int dt = 0; dt < DT; dt++) oacc[a][dt] = mma_acc_b<T, D>(Vs, 32 * sub, dt, s, lane, oacc[a][dt]);
-            }
-        };
-
-        int it = 0;
-        for (int kt0 = 0; kt0 < kv_end; kt0 += 64, it++) {
-            const T* Ks = Kb + (it & 1) * 2 * IMG;
-            const T* Vs = Ks + IMG;
-            const bool more = kt0 + 64 < kv_end;
-            if (more) {
-                sk.load(kg, rs, kt0 + 64, Tn, tid);
-                sv.load(vg, rs, kt0 + 64, Tn, tid);
-            }
-            if (kt0 + 64 <= qb * 256) {
-                // interior tile: every key is below every query row of the workgroup.  The K fragments are read from LDS once
-                // and feed both sub-blocks' score MFMAs, which are all issued before the first softmax.  (Sharing the V
-                // fragments as well costs 32 more registers: the kernel then spills inside this loop.)
-                bf16x8 kf[2][NS];
-#pragma unroll
-                for (int sub = 0; sub < 2; sub++)
-#pragma unroll
-                    for (int s = 0; s < NS; s++) kf[sub][s] = ld_kfrag(Ks, S, sub, s, lane);
-                f32x16 sc[2][2];
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int sub = 0; sub < 2; sub++) {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) sc[a][sub][r] = 0.f;
-#pragma unroll
-                        for (int s = 0; s < NS; s++) sc[a][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][s], qf[a][s], sc[a][sub], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    softmax64(a, sc[a][0], sc[a][1], kt0);
-#pragma unroll
-                    for (int dt = 0; dt < DT; dt++) {
-                        oacc[a][dt] = mma_acc_b<T, D>(Vs, 0, dt, sc[a][0], lane, oacc[a][dt]);
-                        oacc[a][dt] = mma_acc_b<T, D>(Vs, 32, dt, sc[a][1], lane, oacc[a][dt]);
-                    }
-                }
-            } else {
-                tile_a(0, kt0, Ks, Vs);
-                tile_a(1, kt0, Ks, Vs);
-            }
-            if (more) {
-                T* nbuf = Kb + ((it & 1) ^ 1) * 2 * IMG;
-                sk.store(nbuf, tid);
-                sv.store(nbuf + IMG, tid);
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const float ltot = half_sum(lsum[a]);
-            const float inv = (DROP ? drop.scale : 1.0f) / ltot;
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++) store_t_tile<T, D>(og, E, q[a], qvalid[a], dt, oacc[a][dt], inv, h);
-            if (qvalid[a] && h == 0) lse[(int64_t)by * Tn + q[a]] = m[a] * scale + logf(ltot);
-        }
-    }
-}
-
-// =================================================================================================
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
 // With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
 // =================================================================================================
@@ -1082,21 +860,8 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
     dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
     const double flops = 2.0 * B * H * (double)Tn * Tn * D;      // QK^T + PV on the unmasked half
     PROF_START(3, s);
-    bool done = false;
-    if constexpr (std::is_same<T, bf16_t>::value && (D == 64 || D == 32)) {
-        // 64 query rows per wave (attn_fwd2_kernel) once a (batch, head) has at least two 256-row blocks
-        static const int force = [] { const char* e = getenv("COMPOSER_ATTN_FWD"); return e ? atoi(e) : 0; }();   // 1: 32-row kernel, 2: 64-row kernel
-        if ((Tn >= 512 && force != 1) || force == 2) {
-            dim3 grid2((cdiv(Tn, 256) + 1) / 2, B * H);
-            if (d.thr) attn_fwd2_kernel<D, true><<<grid2, 256, smem, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
-            else attn_fwd2_kernel<D, false><<<grid2, 256, smem, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
-            done = true;
-        }
-    }
-    if (!done) {
-        if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
-        else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
-    }
+    if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
+    else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
     PROF_STOP(3, s, flops);
     KERNEL_CHECK();
     return CMP_OK;
