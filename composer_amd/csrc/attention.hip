@@ -17,6 +17,9 @@
 //   "transposed" A operands (V^T, K^T, Q^T, dO^T) come from row-major LDS images through
 //   ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (fp32).
 #include "common.h"
+#ifndef ATTN_DIAG
+#define ATTN_DIAG 0
+#endif
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -353,6 +356,10 @@ __device__ __forceinline__ void colsum_t_tiles(float* __restrict__ bias_grad, bo
 // Causal work balance: query block i needs i+1 key tiles.  A workgroup takes the PAIR (nb-1-x, x) -- heavy one
 // first -- so every workgroup does nb+1 tiles (the middle block of an odd count runs alone).  grid.x = (nb+1)/2.
 __device__ __forceinline__ int pair_block(int ph, int nb, int x) {
+#ifdef ATTN_UNPAIRED
+    // measurement variant: one query block per workgroup, heaviest first (grid.x = nb)
+    return ph == 0 ? nb - 1 - x : -1;
+#endif
     const int hi = nb - 1 - x;
     if (ph == 0) return hi;
     return x < hi ? x : -1;
@@ -361,13 +368,20 @@ __device__ __forceinline__ int pair_block(int ph, int nb, int x) {
 // XCD-aware block mapping: consecutive workgroup ids go to different XCDs (id mod 8), so the gridDim.x workgroups
 // that share one (batch, head)'s K/V (Q/dO) would land on different L2s.  Re-deal: XCD x takes (batch, head) rows
 // x, x+8, ... and runs the gridDim.x blocks of a row on consecutive slots -> one L2 serves the row's tile re-reads.
-__device__ __forceinline__ void xcd_block(int& bx, int& by) {
+// With H a multiple of 8 that alone would give every (batch, head) row of one XCD the SAME head index (by = 8k + xcd), i.e.
+// the same 128-byte column slice of the [B,T,3E] tensor for every K/V/Q tile read through that L2 -- rows 3E*2 bytes apart,
+// a fixed subset of its channels.  The head index is therefore rotated by the batch index (a bijection inside a batch).
+__device__ __forceinline__ void xcd_block(int& bx, int& by, int H) {
     const int gx = gridDim.x, gy = gridDim.y;
     if (gy & 7) { bx = blockIdx.x; by = blockIdx.y; return; }
     const int L = blockIdx.x + gx * blockIdx.y;          // dispatch order: x fastest
     const int xcd = L & 7, slot = L >> 3;
     bx = slot % gx;
     by = (slot / gx) * 8 + xcd;
+#ifndef ATTN_NO_HEAD_ROTATE
+    const int bb = by / H;
+    by = bb * H + (by % H + bb) % H;
+#endif
 }
 
 // =================================================================================================
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
-    xcd_block(bx, by);
+    xcd_block(bx, by, H);
     const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;                        // row stride of qkv
@@ -427,10 +441,12 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
             const T* Ks = Kb + (it & 1) * 2 * IMG;
             const T* Vs = Ks + IMG;
             const bool more = kt0 + 64 < kv_end;
+#if ATTN_DIAG != 5
             if (more) {
                 sk.load(kg, rs, kt0 + 64, Tn, tid);
                 sv.load(vg, rs, kt0 + 64, Tn, tid);
             }
+#endif
             // Fast path (throughput mode): all 64 keys of the tile are at or below every query of this wave -> no
             // masking; both 32-key sub-tiles go through ONE softmax step: 8 score MFMAs back to back, one row-max exchange
             // and one rescale vote per 64 keys, 32 exponentials, 8 PV MFMAs.
@@ -439,9 +455,21 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
                 f32x16 s0, s1;
 #pragma unroll
                 for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
+                // ATTN_DIAG (measurement builds only -- results are wrong; tools/kbench.py attn):
+                // 1 no exponentials, 2 no PV MFMAs, 3 no score MFMAs / K fragment reads, 4 no staging stores and no barrier,
+                // 5 no global loads either, 6 no row max / rescale
+#if ATTN_DIAG == 3
+#pragma unroll
+                for (int r = 0; r < 16; r++) { s0[r] = (float)(kt0 + r) * 1e-3f; s1[r] = (float)(kt0 - r) * 1e-3f; }
+#else
                 s0 = mma_rows<T, D>(Ks, 0, qf, lane, s0);
                 s1 = mma_rows<T, D>(Ks, 32, qf, lane, s1);
+#endif
+#if ATTN_DIAG == 6
+                const float mloc = 0.f;
+#else
                 const float mloc = half_max(fmaxf(max16(s0), max16(s1)));
+#endif
                 const float mnew = fmaxf(m, mloc);
                 if (!__all(mnew == m)) {
                     const float alpha = fast_exp2((m - mnew) * c2);
@@ -454,18 +482,28 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
                 }
                 const float mc = m * c2;
                 f32x2 ps = {0.f, 0.f};
+#if ATTN_DIAG == 1
+#pragma unroll
+                for (int r = 0; r < 16; r++) { s0[r] = fmaf(s0[r], c2, -mc); s1[r] = fmaf(s1[r], c2, -mc); ps[0] += s0[r]; ps[1] += s1[r]; }
+#else
                 ps = exp2_scaled16(s0, c2, -mc, ps);
                 ps = exp2_scaled16(s1, c2, -mc, ps);
+#endif
                 lsum += ps[0] + ps[1];
                 if constexpr (DROP) {
                     mask16_qlane<true>(s0, rowh, kt0, h, drop.thr);
                     mask16_qlane<true>(s1, rowh, kt0 + 32, h, drop.thr);
                 }
+#if ATTN_DIAG == 2
+#pragma unroll
+                for (int r = 0; r < 16; r++) { oacc[0][r] += s0[r]; oacc[G::DT - 1][r] += s1[r]; }
+#else
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) {
                     oacc[dt] = mma_acc_b<T, D>(Vs, 0, dt, s0, lane, oacc[dt]);
                     oacc[dt] = mma_acc_b<T, D>(Vs, 32, dt, s1, lane, oacc[dt]);
                 }
+#endif
             } else
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
@@ -533,12 +571,18 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) oacc[dt] = mma_acc_b<T, D>(Vs, 32 * sub, dt, s, lane, oacc[dt]);
             }
+#if ATTN_DIAG == 4 || ATTN_DIAG == 5
+            if (!decltype(interior)::value) {
+#endif
             if (more) {
                 T* nbuf = Kb + ((it & 1) ^ 1) * 2 * IMG;
                 sk.store(nbuf, tid);
                 sv.store(nbuf + IMG, tid);
             }
             __syncthreads();
+#if ATTN_DIAG == 4 || ATTN_DIAG == 5
+            }
+#endif
         };
         int kt0 = 0, it = 0;
         const int interior_end = EXACT ? 0 : qb * 128;                 // keys below every query row of the block
@@ -572,7 +616,7 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
-    xcd_block(bx, by);
+    xcd_block(bx, by, H);
     const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
@@ -705,7 +749,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
-    xcd_block(bx, by);
+    xcd_block(bx, by, H);
     const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
@@ -857,7 +901,11 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
+#ifdef ATTN_UNPAIRED
+    dim3 grid(cdiv(Tn, 128), B * H);
+#else
     dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
+#endif
     const double flops = 2.0 * B * H * (double)Tn * Tn * D;      // QK^T + PV on the unmasked half
     PROF_START(3, s);
     if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
