@@ -1,9 +1,15 @@
 """Builds composer_amd/lib/libcomposer_hip.so from composer_amd/csrc/*.hip with hipcc for gfx950.
 
 In-tree build (the .so travels to the GPU box with the repo snapshot).  Object files are cached under
-composer_amd/csrc/_obj and rebuilt when a source or header is newer.
-    python -m composer_amd.build [--force]
+composer_amd/csrc/_obj keyed by the SHA-256 of (source, every header, compiler flags, hipcc version): an object is rebuilt
+when that key changes, never by file time.  composer_amd/lib/BUILD_INFO.json records, per source, the key and whether this
+call compiled it or reused the cached object, plus the key the linked library was built from -- `verify()` (used by
+__graft_entry__.build and the ABI test) fails if the library on disk does not match the sources in the tree.
+    python -m composer_amd.build [--force] [--asan]
+--asan: host-side AddressSanitizer build (device code unchanged) into lib/libcomposer_hip_asan.so; CPU container only.
 """
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -27,46 +33,94 @@ def _hipcc():
     return "hipcc"
 
 
-def _newest_header():
-    t = 0.0
+def _hipcc_version():
+    try:
+        return subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip().split("\n")[0]
+    except Exception:
+        return "unknown"
+
+
+def _headers():
+    out = []
     for d in (CSRC, os.path.join(ROOT, "include")):
-        for f in os.listdir(d):
+        for f in sorted(os.listdir(d)):
             if f.endswith(".h"):
-                t = max(t, os.path.getmtime(os.path.join(d, f)))
-    return t
+                out.append(os.path.join(d, f))
+    return out
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+def source_key(src, flags):
+    h = hashlib.sha256()
+    h.update(("\0".join(flags) + "\0" + _hipcc_version()).encode())
+    for path in [os.path.join(CSRC, src)] + _headers():
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def _compile(src, force, flags, tag=""):
+    obj = os.path.join(OBJ, tag + src.replace(".hip", ".o"))
+    keyfile = obj + ".key"
+    key = source_key(src, flags)
+    if not force and os.path.exists(obj) and os.path.exists(keyfile) and open(keyfile).read().strip() == key:
+        return obj, False, key
     sp = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(sp)
-            and os.path.getmtime(obj) >= _newest_header()):
-        return obj, False
-    cmd = [_hipcc()] + FLAGS + ["-c", sp, "-o", obj]
+    cmd = [_hipcc()] + flags + ["-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-4000:]))
-    return obj, True
+    open(keyfile, "w").write(key)
+    return obj, True, key
 
 
-def build(force=False, verbose=True):
+def _lib_key(keys):
+    return hashlib.sha256("".join(keys).encode()).hexdigest()
+
+
+def build(force=False, verbose=True, asan=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    flags = FLAGS + (["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-g", "-fno-omit-frame-pointer"] if asan else [])
+    tag = "asan_" if asan else ""
+    lib = os.path.join(LIBDIR, "libcomposer_hip_asan.so") if asan else LIB
+    info_path = os.path.join(LIBDIR, "BUILD_INFO_asan.json" if asan else "BUILD_INFO.json")
     with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), SOURCES))
-    objs = [o for o, _ in res]
-    if any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + \
-              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        res = list(ex.map(lambda s: _compile(s, force, flags, tag), SOURCES))
+    objs = [o for o, _, _ in res]
+    lib_key = _lib_key([k for _, _, k in res])
+    old = {}
+    try:
+        old = json.load(open(info_path))
+    except Exception:
+        pass
+    relink = any(c for _, c, _ in res) or not os.path.exists(lib) or old.get("library_key") != lib_key
+    if relink:
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"] + (["-fsanitize=address", "-shared-libsan"] if asan else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
-        if verbose:
-            print("built", LIB)
-    elif verbose:
-        print("up to date:", LIB)
-    return LIB
+    info = {"library": os.path.basename(lib), "library_key": lib_key, "hipcc": _hipcc_version(), "arch": ARCH,
+            "sources": {s: {"key": k, "compiled_by_this_call": bool(c)} for s, (_, c, k) in zip(SOURCES, res)},
+            "relinked_by_this_call": bool(relink)}
+    json.dump(info, open(info_path, "w"), indent=1)
+    if verbose:
+        for s, (_, c, _) in zip(SOURCES, res):
+            print("  %-18s %s" % (s, "compiled" if c else "cached object (source key unchanged)"))
+        print(("built " if relink else "up to date: ") + lib)
+    return lib
+
+
+def verify():
+    """True when lib/libcomposer_hip.so was linked from exactly the sources + headers + flags now in the tree."""
+    try:
+        info = json.load(open(os.path.join(LIBDIR, "BUILD_INFO.json")))
+    except Exception:
+        return False
+    if not os.path.exists(LIB):
+        return False
+    return info.get("library_key") == _lib_key([source_key(s, FLAGS) for s in SOURCES])
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, asan="--asan" in sys.argv)

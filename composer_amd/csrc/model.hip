@@ -14,6 +14,7 @@
 //     x_in, u=LN1(x_in), qkv, att, r=u+proj, n=LN2(r), fc (pre-GELU), g=gelu(fc); LN stats and LSE in fp32.
 #include "model.h"
 #include <stdarg.h>
+#include <dlfcn.h>
 
 static thread_local char g_err[1024] = "";
 void cmp_set_error(const char* fmt, ...) {
@@ -75,6 +76,33 @@ extern "C" int cmp_prof_end(double* total_ms, int64_t* launches, double* work) {
     g_prof_used = 0;
     return CMP_OK;
 }
+
+// -------------------------------------------------------------------------------------------------
+// roctx ranges (COMPOSER_ROCTX=1): forward / loss / backward (per block) / adam show up as named ranges in
+// `rocprofv3 --marker-trace --kernel-trace`.  libroctx64 is looked up at run time; absent or disabled = no-ops.
+// -------------------------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("COMPOSER_ROCTX");
+        if (!e || e[0] != '1') return;
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr;
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+};
+}  // namespace
 
 // -------------------------------------------------------------------------------------------------
 // context
@@ -513,6 +541,7 @@ static int rows_copy(cmp_model* m, const void* src, void* dst, int B, int Tn, in
 // kernel runs over all past_len + T rows (the mask of transformer.py:290-301 for nd = T, ns = past_len + T is the last T
 // rows of the square one) and the T new output rows are taken out again.
 int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step, int past_len) {
+    Range range_("composer.forward");
     hipStream_t s = m->ctx->stream;
     struct RoleGuard {
         cmp_model* m;
@@ -563,6 +592,7 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
 }
 
 static int loss(cmp_model* m, const int32_t* y_dev, int M, bool want_grad) {
+    Range range_("composer.loss");
     hipStream_t s = m->ctx->stream;
     CHECK_RC(cmp_k_softmax_xent(s, m->logits, m->ldz, y_dev, want_grad ? m->dlogits : nullptr, m->row_loss, m->row_correct, M,
                                 m->V, 1.0f / (float)M, m->dtype));
@@ -595,6 +625,7 @@ static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end) {
 
 // reverse mode of forward() (tf.GradientTape, transformer.py:916-920); formulas in SURVEY appendix A
 static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t step, bool allreduce) {
+    Range range_("composer.backward");
     hipStream_t s = m->ctx->stream;
     const int E = m->E, M = B * T, dt = m->dtype, V = m->V;
     const float pr = m->cfg.resid_dropout, pa = m->cfg.attn_dropout;
@@ -695,6 +726,7 @@ static int dp_metrics_begin(cmp_model* m) {
 }
 
 static int adam(cmp_model* m, float lr) {
+    Range range_("composer.adam");
     cmp_ctx* c = m->ctx;
     float gscale = 1.0f;
     if (c->comm) {

@@ -46,6 +46,13 @@ def test_product_path_fails_loudly_without_gpu(lib):
         Transformer(390, 64, 32, 1, 4)
 
 
+def test_library_on_disk_was_built_from_the_sources_in_the_tree():
+    """The .so ships prebuilt to the GPU box: its BUILD_INFO.json key must equal the key of the current sources, headers,
+    flags and compiler (composer_amd/build.py), so a stale library cannot pass for the tree's code."""
+    from composer_amd import build as b
+    assert b.verify(), "run `python -m composer_amd.build`: lib/libcomposer_hip.so is older than the sources"
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "composer_amd")):
         for f in files:
@@ -53,3 +60,15 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "transformer_oracle" not in src, f
+
+
+@pytest.mark.skipif(os.environ.get("COMPOSER_TEST_ASAN") != "1", reason="set COMPOSER_TEST_ASAN=1 (builds the host-ASan library, ~1 min)")
+def test_host_asan_build_runs_the_error_paths_clean():
+    """`python -m composer_amd.build --asan` (host-side AddressSanitizer, device code unchanged) + tools/asan_probe.py."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-m", "composer_amd.build", "--asan"], cwd=root, check=True)
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "--print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asan_probe.py")], capture_output=True, text=True,
+                       env=dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "asan probe done" in r.stdout and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
