@@ -150,7 +150,13 @@ template <typename T, int D> struct Stager {
         for (int i = 0; i < NC; i++) {
             const int c = tid + 256 * i;
             const int row = c / CPR, cc = c % CPR;
+            // whole chunks per thread (every D >= 32): unconditional, so the stores are straight-line code that can be scheduled
+            // among the tile's last MFMAs instead of four exec-masked blocks behind them
+#ifdef ATTN_COND_STORE
             if (c < 64 * CPR) {
+#else
+            if ((64 * CPR) % 256 == 0 || c < 64 * CPR) {
+#endif
                 if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
                     for (int j = 0; j < VN; j++) img[row * S + cc * VN + j] = r[i].get(j);

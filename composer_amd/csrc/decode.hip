@@ -114,7 +114,9 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // in flight at once (K <= 64*4*GV_MAXI).  IN: 0 plain copy, 1 LayerNorm (every workgroup recomputes the row statistics of
 // the 2-8 KiB input: cheaper than another launch), 2 combine of the split-key attention partials.
 #define GV_MAXI 12
-#define ATT_SPLITS 8        // 4: 206 us/token, 8: 194, 16: 222 (the combine in the next GEMV grows), same-box
+#ifndef ATT_SPLITS
+#define ATT_SPLITS 4        // round-2 kernels, same box: 4: 124.4 us/token, 8: 128-129, 16: 128.6 (round-1 kernels: 206 / 194 / 222)
+#endif
 template <int ACT, int IN>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, float eps,
@@ -387,32 +389,33 @@ __device__ __forceinline__ float wave_max2(float v) {
 
 #define PSTRIDE(D) ((D) + 4)          // attention partial record: o[D], running max, sum, 2 pad floats (16-byte aligned rows)
 
-// y[n] = act( IN(x) . Wt[n,:] + bias[n] ) + resid[n]; one wave per output column, blockDim.x / 64 columns per workgroup.
-template <int ACT, int IN>
+// y[n] = act( IN(x) . Wt[n,:] + bias[n] ) + resid[n]; a wave owns CW adjacent output columns, blockDim.x / 64 waves per workgroup.
+// KI = 16-byte chunks of a row per lane (K <= 256 * KI): the loads are unrolled KI times, so the narrow model widths do not carry
+// twelve predicated slots.  CW = 2 halves the number of waves to dispatch for the wide outputs and shares the input prologue.
+template <int ACT, int IN, int KI, int CW>
 __global__ __launch_bounds__(256) void dec_gemv2_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, float eps,
                                                         const float* __restrict__ Wt, const float* __restrict__ bias,
                                                         const float* __restrict__ resid, float* __restrict__ y,
                                                         float* __restrict__ u_out, int K, int N, int D) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (n >= N) return;                                            // whole wave; nothing below synchronises waves
-    const float* wr = Wt + (int64_t)n * K;
-    f32x4 wv[GV_MAXI], xv[GV_MAXI];
+    const int n0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * CW;
+    if (n0 >= N) return;                                           // whole wave; nothing below synchronises waves
+    f32x4 wv[CW][KI], xv[KI];
 #pragma unroll
-    for (int i = 0; i < GV_MAXI; i++) {
-        const int k = (lane + 64 * i) * 4;
-        // streamed once per token by one wave: non-temporal (MI355X_MICROARCH "nt-weights": shorter issue-to-landed time)
-#ifdef DEC_NO_NT
-        wv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(wr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#else
-        wv[i] = (k < K) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + k)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#endif
+    for (int c = 0; c < CW; c++) {
+        const float* wr = Wt + (int64_t)min(n0 + c, N - 1) * K;
+#pragma unroll
+        for (int i = 0; i < KI; i++) {
+            const int k = (lane + 64 * i) * 4;
+            // streamed once per token by one wave: non-temporal (MI355X_MICROARCH "nt-weights": shorter issue-to-landed time)
+            wv[c][i] = (k < K) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + k)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     if (IN == 2) {
         // x: attention partials [H][ATT_SPLITS][PSTRIDE]; K = H*D.  Chunk k..k+3 lies in head k/D.
 #pragma unroll
-        for (int i = 0; i < GV_MAXI; i++) {
+        for (int i = 0; i < KI; i++) {
             const int k = (lane + 64 * i) * 4;
             f32x4 num = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (k < K) {
@@ -439,15 +442,15 @@ __global__ __launch_bounds__(256) void dec_gemv2_kernel(const float* __restrict_
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < GV_MAXI; i++) {
+        for (int i = 0; i < KI; i++) {
             const int k = (lane + 64 * i) * 4;
             xv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(x + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (IN == 1) {
-            f32x4 gv[GV_MAXI], bv[GV_MAXI];
+            f32x4 gv[KI], bv[KI];
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < GV_MAXI; i++) {
+            for (int i = 0; i < KI; i++) {
                 const int k = (lane + 64 * i) * 4;
                 gv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(ln_g + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 bv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(ln_b + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void dec_gemv2_kernel(const float* __restrict_
             const float mu = wave_sum2(s) / (float)K;
             float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < GV_MAXI; i++) {
+            for (int i = 0; i < KI; i++) {
                 const int k = (lane + 64 * i) * 4;
                 if (k < K) {
                     const f32x4 dv = xv[i] - mu;
@@ -466,25 +469,29 @@ __global__ __launch_bounds__(256) void dec_gemv2_kernel(const float* __restrict_
             const float var = wave_sum2(q) / (float)K;
             const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
-            for (int i = 0; i < GV_MAXI; i++) xv[i] = (xv[i] - mu) * rs * gv[i] + bv[i];      // padding lanes: gamma = beta = 0
+            for (int i = 0; i < KI; i++) xv[i] = (xv[i] - mu) * rs * gv[i] + bv[i];      // padding lanes: gamma = beta = 0
         }
-        if (u_out && n == 0) {
+        if (u_out && n0 == 0) {
 #pragma unroll
-            for (int i = 0; i < GV_MAXI; i++) {
+            for (int i = 0; i < KI; i++) {
                 const int k = (lane + 64 * i) * 4;
                 if (k < K) *reinterpret_cast<f32x4*>(u_out + k) = xv[i];
             }
         }
     }
-    float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < GV_MAXI; i++) acc += (xv[i][0] * wv[i][0] + xv[i][1] * wv[i][1]) + (xv[i][2] * wv[i][2] + xv[i][3] * wv[i][3]);
-    float v = wave_sum2(acc);
-    if (lane == 0) {
-        if (bias) v += bias[n];
-        if (ACT == 1) v = gelu_f<true>(v);
-        if (resid) v += resid[n];
-        y[n] = v;
+    for (int c = 0; c < CW; c++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < KI; i++) acc += (xv[i][0] * wv[c][i][0] + xv[i][1] * wv[c][i][1]) + (xv[i][2] * wv[c][i][2] + xv[i][3] * wv[c][i][3]);
+        float v = wave_sum2(acc);
+        const int n = n0 + c;
+        if (lane == 0 && n < N) {
+            if (bias) v += bias[n];
+            if (ACT == 1) v = gelu_f<true>(v);
+            if (resid) v += resid[n];
+            y[n] = v;
+        }
     }
 }
 
@@ -608,6 +615,12 @@ __global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restric
     const float* z = logits + ldz_row_off;
     const unsigned ctr = st->rng;
     const int pos0 = st->pos, adv = st->advance, nprod = st->produced, capI = st->cap, Wn = st->W;
+    int pos = first ? pos0 : (adv ? pos0 + 1 : 0);
+    const int posc = min(pos, Wn - 1);     // host refuses to step past the table; never index outside it
+    // the position row does not depend on the sampled id: requested now, consumed after the argmax
+    float pe[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int e = tid + 256 * i; pe[i] = e < E ? wpe[(int64_t)posc * E + e] : 0.f; }
     float best = -INFINITY;
     int arg = 0x7fffffff;
     const float inv_t = temperature > 0.f ? 1.0f / temperature : 0.f;
@@ -641,7 +654,6 @@ __global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restric
     for (int w = 1; w < 4; w++)
         if (bv[w] > fb || (bv[w] == fb && bi[w] < id)) { fb = bv[w]; id = bi[w]; }
     id = min(max(id, 0), V - 1);         // all-NaN logits leave the sentinel index: never address outside wte
-    int pos = first ? pos0 : (adv ? pos0 + 1 : 0);
     if (tid == 0) {
         if (nprod < capI) ids[nprod] = id;
         st->produced = nprod + 1;
@@ -649,8 +661,9 @@ __global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restric
         st->token = id;
         st->pos = pos;
     }
-    if (pos >= Wn) pos = Wn - 1;         // host refuses to step past the table; never index outside it
-    for (int e = tid; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)pos * E + e];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int e = tid + 256 * i; if (e < E) x[e] = wte[(int64_t)id * E + e] + pe[i]; }
+    for (int e = tid + 1024; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)posc * E + e];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -670,14 +683,23 @@ static int launch_gemv(hipStream_t s, int act, int in_mode, const float* x, cons
 static int launch_gemv2(hipStream_t s, int act, int in_mode, const float* x, const float* g, const float* b, float eps,
                         const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D) {
     CMP_REQUIRE(K % 4 == 0 && K <= 256 * GV_MAXI, "decode gemv: K=%d unsupported (max %d)", K, 256 * GV_MAXI);
-    // one wave per column; 4, 2 or 1 waves per workgroup so that the narrow outputs still give every CU a workgroup
+    // CW = 2 columns per wave for the wide outputs of the narrow-K launches; 4, 2 or 1 waves per workgroup so that the narrow
+    // outputs still give every CU a workgroup
+#ifdef DEC_NO_CW2
+    const int cw = 1;
+#else
+    const int cw = (K <= 512 && N >= 1024) ? 2 : 1;
+#endif
+    const int waves = cdiv(N, cw);
     int block = 256;
-    while (block > 64 && cdiv(N, block / 64) < 256) block >>= 1;
-    const int grid = cdiv(N, block / 64);
-#define GV(A, I) dec_gemv2_kernel<A, I><<<grid, block, 0, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D)
-    if (act == 1) { if (in_mode == 1) GV(1, 1); else if (in_mode == 2) GV(1, 2); else GV(1, 0); }
-    else { if (in_mode == 1) GV(0, 1); else if (in_mode == 2) GV(0, 2); else GV(0, 0); }
-#undef GV
+    while (block > 64 && cdiv(waves, block / 64) < 256) block >>= 1;
+    const int grid = cdiv(waves, block / 64);
+#define GV3(A, I, KI, CW) dec_gemv2_kernel<A, I, KI, CW><<<grid, block, 0, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D)
+#define GV2(A, I) do { if (K <= 512) { if (cw == 2) GV3(A, I, 2, 2); else GV3(A, I, 2, 1); } else GV3(A, I, GV_MAXI, 1); } while (0)
+    if (act == 1) { if (in_mode == 1) GV2(1, 1); else if (in_mode == 2) GV2(1, 2); else GV2(1, 0); }
+    else { if (in_mode == 1) GV2(0, 1); else if (in_mode == 2) GV2(0, 2); else GV2(0, 0); }
+#undef GV2
+#undef GV3
     KERNEL_CHECK();
     return CMP_OK;
 }
