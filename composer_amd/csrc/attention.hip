@@ -447,7 +447,12 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
             const T* Ks = Kb + (it & 1) * 2 * IMG;
             const T* Vs = Ks + IMG;
             const bool more = kt0 + 64 < kv_end;
-#if ATTN_DIAG != 5
+#if ATTN_DIAG == 7          // every tile load re-reads tile 0 (L1 / L2 hits): instruction issue without the traffic
+            if (more) {
+                sk.load(kg, rs, decltype(interior)::value ? 0 : kt0 + 64, Tn, tid);
+                sv.load(vg, rs, decltype(interior)::value ? 0 : kt0 + 64, Tn, tid);
+            }
+#elif ATTN_DIAG != 5
             if (more) {
                 sk.load(kg, rs, kt0 + 64, Tn, tid);
                 sv.load(vg, rs, kt0 + 64, Tn, tid);
