@@ -187,15 +187,39 @@ template <bool EXACT> __device__ __forceinline__ float gelu_grad_f(float x) {
     return sg * (1.0f + x * (1.0f - sg) * (2.0f * GELU_C + 6.0f * GELU_C * GELU_K * (x * x)));
 }
 
+// Wave-wide sum / max, the same value (and summation order) in every lane.  DPP row operations (quad_perm, row_half_mirror,
+// row_mirror: four vector instructions reduce each row of 16 lanes) + v_readlane of the four row totals -- no ds_bpermute
+// round trips through the LDS crossbar (the __shfl_xor form is six of them per reduction).  WAVE_REDUCE_SHFL selects that
+// form for A/B timing.
+#define CMP_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float cmp_readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef WAVE_REDUCE_SHFL
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+#else
+    v += CMP_DPP_F(v, 0xB1);       // quad_perm(1,0,3,2)
+    v += CMP_DPP_F(v, 0x4E);       // quad_perm(2,3,0,1)
+    v += CMP_DPP_F(v, 0x141);      // row_half_mirror
+    v += CMP_DPP_F(v, 0x140);      // row_mirror
+    return (cmp_readlane_f(v, 0) + cmp_readlane_f(v, 16)) + (cmp_readlane_f(v, 32) + cmp_readlane_f(v, 48));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef WAVE_REDUCE_SHFL
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
+#else
+    v = fmaxf(v, CMP_DPP_F(v, 0xB1));
+    v = fmaxf(v, CMP_DPP_F(v, 0x4E));
+    v = fmaxf(v, CMP_DPP_F(v, 0x141));
+    v = fmaxf(v, CMP_DPP_F(v, 0x140));
+    return fmaxf(fmaxf(cmp_readlane_f(v, 0), cmp_readlane_f(v, 16)), fmaxf(cmp_readlane_f(v, 32), cmp_readlane_f(v, 48)));
+#endif
 }
 
 // vector load/store of 8 (bf16) or 4 (fp32) contiguous elements = 16 bytes
