@@ -63,7 +63,7 @@ def _ld(num: int, payload: bytes) -> bytes:          # length-delimited
 def _scalar_summary(tag: str, value: float) -> bytes:
     tensor = _field(1, 0) + _varint(1) + _ld(2, b'') + _ld(5, struct.pack('<f', value))      # DT_FLOAT, scalar shape, packed float_val
     meta = _ld(1, _ld(1, b'scalars'))
-    val = _ld(1, tag.encode()) + _ld(9, meta) + _ld(8, tensor)
+    val = _ld(1, tag.encode()) + _ld(8, tensor) + _ld(9, meta)          # fields in number order, as protobuf serialisers emit them
     return _ld(1, val)
 
 
