@@ -71,6 +71,18 @@ def _pool():
                                                             ("shape", 2, F.TYPE_MESSAGE, OPT, ".tensorflow.TensorShapeProto", None),
                                                             ("shard_id", 3, F.TYPE_INT32, OPT, None, None), ("offset", 4, F.TYPE_INT64, OPT, None, None),
                                                             ("size", 5, F.TYPE_INT64, OPT, None, None), ("crc32c", 6, F.TYPE_FIXED32, OPT, None, None)]))
+    # trackable_object_graph.proto
+    ref = msg("ObjectReference", [("node_id", 1, F.TYPE_INT32, OPT, None, None), ("local_name", 2, F.TYPE_STRING, OPT, None, None)])
+    ser = msg("SerializedTensor", [("name", 1, F.TYPE_STRING, OPT, None, None), ("full_name", 2, F.TYPE_STRING, OPT, None, None),
+                                   ("checkpoint_key", 3, F.TYPE_STRING, OPT, None, None)])
+    slot = msg("SlotVariableReference", [("original_variable_node_id", 1, F.TYPE_INT32, OPT, None, None), ("slot_name", 2, F.TYPE_STRING, OPT, None, None),
+                                         ("slot_variable_node_id", 3, F.TYPE_INT32, OPT, None, None)])
+    obj = msg("TrackableObject", [("children", 1, F.TYPE_MESSAGE, REP, ".tensorflow.TrackableObjectGraph.TrackableObject.ObjectReference", None),
+                                  ("attributes", 2, F.TYPE_MESSAGE, REP, ".tensorflow.TrackableObjectGraph.TrackableObject.SerializedTensor", None),
+                                  ("slot_variables", 3, F.TYPE_MESSAGE, REP, ".tensorflow.TrackableObjectGraph.TrackableObject.SlotVariableReference", None)],
+              nested=[ref, ser, slot])
+    fd.message_type.add().CopyFrom(msg("TrackableObjectGraph", [("nodes", 1, F.TYPE_MESSAGE, REP, ".tensorflow.TrackableObjectGraph.TrackableObject", None)],
+                                       nested=[obj]))
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     return pool
@@ -80,7 +92,7 @@ def _pool():
 def M():
     pool = _pool()
     get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("tensorflow." + n))
-    return {n: get(n) for n in ("Example", "Event", "Summary", "TensorProto", "BundleHeaderProto", "BundleEntryProto")}
+    return {n: get(n) for n in ("Example", "Event", "Summary", "TensorProto", "BundleHeaderProto", "BundleEntryProto", "TrackableObjectGraph")}
 
 
 def test_example_bytes_parse_with_the_protobuf_runtime_and_back(M):
@@ -163,3 +175,38 @@ def test_bundle_index_entries_parse_with_the_protobuf_runtime(M, tmp_path):
     open(tmp_path / "ckpt-2.data-00000-of-00001", "wb").write(a.tobytes())
     got = tensorbundle.read_bundle(tmp_path / "ckpt-2")
     assert np.array_equal(got["model/w"], a)
+
+
+def test_object_graph_parses_with_the_protobuf_runtime_and_is_a_consistent_tree(M):
+    """The `_CHECKPOINTABLE_OBJECT_GRAPH` entry of a checkpoint written by `bundle_from_state`: a TrackableObjectGraph whose tree
+    spells every checkpoint key from the root, with the Adam slots as slot_variables of the optimizer node."""
+    state = {"model/wte/weight": np.zeros((3, 2), np.float32), "model/decoder_blocks/0/attn/c_attn/bias": np.zeros((1, 6), np.float32),
+             "optimizer/m/wte/weight": np.zeros((3, 2), np.float32), "optimizer/v/wte/weight": np.zeros((3, 2), np.float32),
+             "optimizer/m/decoder_blocks/0/attn/c_attn/bias": np.zeros((1, 6), np.float32),
+             "optimizer/v/decoder_blocks/0/attn/c_attn/bias": np.zeros((1, 6), np.float32), "optimizer/iter": np.int64(5)}
+    bundle = tensorbundle.bundle_from_state(state, {"step": 6, "epoch": 2, "save_counter": 1})
+    g = M["TrackableObjectGraph"]()
+    g.ParseFromString(bundle[tensorbundle.OBJECT_GRAPH_KEY])
+    assert g.SerializeToString(deterministic=True) == bundle[tensorbundle.OBJECT_GRAPH_KEY]
+    # every key reachable by walking local_names from node 0
+    paths = {}
+
+    def walk(i, prefix):
+        for a in g.nodes[i].attributes:
+            paths[a.checkpoint_key] = (prefix, a.name)
+        for c in g.nodes[i].children:
+            walk(c.node_id, prefix + [c.local_name])
+    walk(0, [])
+    plain = [k for k in bundle if k.endswith(tensorbundle.VALUE_SUFFIX) and tensorbundle.SLOT_MARK not in k]
+    for k in plain:
+        assert paths[k] == (k[:-len(tensorbundle.VALUE_SUFFIX)].split("/"), "VARIABLE_VALUE"), k
+    # slots: optimizer node -> (variable node, slot name, slot node holding the key)
+    opt = next(c.node_id for c in g.nodes[0].children if c.local_name == "optimizer")
+    seen = set()
+    for sv in g.nodes[opt].slot_variables:
+        (attr,) = g.nodes[sv.slot_variable_node_id].attributes
+        var_key = next(k for k, (pth, _) in paths.items() if any(a.checkpoint_key == k for a in g.nodes[sv.original_variable_node_id].attributes))
+        assert attr.checkpoint_key == var_key[:-len(tensorbundle.VALUE_SUFFIX)] + tensorbundle.SLOT_MARK + "optimizer/" + sv.slot_name + tensorbundle.VALUE_SUFFIX
+        seen.add(attr.checkpoint_key)
+    assert seen == {k for k in bundle if tensorbundle.SLOT_MARK in k}
+    assert sorted(tensorbundle.checkpoint_keys_of_graph(bundle[tensorbundle.OBJECT_GRAPH_KEY])) == sorted(k for k in bundle if k.endswith(tensorbundle.VALUE_SUFFIX))
