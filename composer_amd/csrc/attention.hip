@@ -361,11 +361,11 @@ __device__ __forceinline__ void colsum_t_tiles(float* __restrict__ bias_grad, bo
 
 // Causal work balance: query block i needs i+1 key tiles.  A workgroup takes the PAIR (nb-1-x, x) -- heavy one
 // first -- so every workgroup does nb+1 tiles (the middle block of an odd count runs alone).  grid.x = (nb+1)/2.
+// When B*H is small (the default config at batch 1: 16 (batch, head) rows) the launcher gives every block its own workgroup
+// instead (gridDim.x == nb, heaviest first): twice the workgroups, each half as long; with many rows the pairing is faster
+// (same-box A/B at B*H = 1024: 303-317 us paired, 341-346 us unpaired).
 __device__ __forceinline__ int pair_block(int ph, int nb, int x) {
-#ifdef ATTN_UNPAIRED
-    // measurement variant: one query block per workgroup, heaviest first (grid.x = nb)
-    return ph == 0 ? nb - 1 - x : -1;
-#endif
+    if ((int)gridDim.x == nb && nb > 1) return ph == 0 ? nb - 1 - x : -1;
     const int hi = nb - 1 - x;
     if (ph == 0) return hi;
     return x < hi ? x : -1;
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
 
     for (int ph = 0; ph < 2; ph++) {
         // light/heavy are mirrored w.r.t. the forward: key block 0 is the heavy one
-        const int kb = ph == 0 ? bx : (bx < nb - 1 - bx ? nb - 1 - bx : -1);
+        const int kb = ((int)gridDim.x == nb && nb > 1) ? (ph == 0 ? bx : -1) : (ph == 0 ? bx : (bx < nb - 1 - bx ? nb - 1 - bx : -1));
         if (kb < 0) break;
         const int k0w = kb * 128 + wave * 32;
         const int key = k0w + (lane & 31);
@@ -905,6 +905,11 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
 // =================================================================================================
 // host launchers
 // =================================================================================================
+// grid.x: block pairs, or single blocks when the paired grid would leave most of the 256 CUs x 2-3 workgroups without work
+static int attn_grid_x(int Tn, int BH) {
+    const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2;
+    return (nb > 1 && (int64_t)pairs * BH < 512) ? nb : pairs;
+}
 template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
@@ -912,11 +917,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-#ifdef ATTN_UNPAIRED
-    dim3 grid(cdiv(Tn, 128), B * H);
-#else
-    dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
-#endif
+    dim3 grid(attn_grid_x(Tn, B * H), B * H);
     const double flops = 2.0 * B * H * (double)Tn * Tn * D;      // QK^T + PV on the unmasked half
     PROF_START(3, s);
     if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
@@ -928,7 +929,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
 template <typename T, int D>
 static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                       void* dqkv, int B, int Tn, int H, float scale, DropCfg d, float* bias_grad) {
-    dim3 grid((cdiv(Tn, 128) + 1) / 2, B * H);
+    dim3 grid(attn_grid_x(Tn, B * H), B * H);
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem + 1536 > 65536) {
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_dq_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

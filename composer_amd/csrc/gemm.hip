@@ -1504,7 +1504,11 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
         const bool fast = km_ok && a_span < 0x7FFFFFF0ll && b_span < 0x7FFFFFF0ll && ldc % 8 == 0 && (out_fp32 || N % 8 == 0) &&
                           (!aux || (ldaux % 8 == 0 && N % 8 == 0)) && (!resid || (ldr % 8 == 0 && N % 8 == 0)) && !(flags & 2);
         PROF_START(cls, s);
-        const bool big = fast && !(flags & 4) && ((flags & (8 | 16)) || ((int64_t)M * N >= 512ll * 512));
+        // 256x256 persistent tiles once they give most of the chip a tile (or a split-K launch sizes its own item count); the
+        // 128x128 kernel (2 workgroups per CU) below that: at the default config (E=256, B=1: M=1024) the 256-tile kernels ran 4-16
+        // workgroups on 256 CUs (27 us for a 4-tile launch)
+        const int64_t t256 = (int64_t)cdiv(M, 256) * cdiv(N, 256);
+        const bool big = fast && !(flags & 4) && ((flags & (8 | 16)) || ((int64_t)M * N >= 512ll * 512 && (t256 >= 192 || splitk_req > 1)));
         // measured at the C2 shapes (tools/kbench.py): both-K-contiguous (dgrad) is fastest on the 2-stage BK=64 kernel
         // (its DMA pieces are whole 128-byte lines); forward and wgrad on the 4-stage BK=32 deep pipeline.
         const bool prefer_p4 = !(!ta && tb);
