@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const T* __restrict__ resid,
                                      T* __restrict__ dx, float* __restrict__ ws, int rows, int E,
-                                     T* __restrict__ dmask, int want_colsum, DropCfg drop) {
+                                     T* __restrict__ dmask, int want_colsum, DropCfg drop,
+                                     float* __restrict__ direct_g, float* __restrict__ direct_b, float* __restrict__ direct_cs) {
     // optional fused consumer prologue: the output dx is the gradient of a residual branch's dropout output
     // (x + dropout(proj(..))): dmask = dx * mask/(1-p) feeds that projection's wgrad/dgrad and its column sums are the
     // projection's bias gradient (third partial, ws[wg][2] -> cs)
@@ -284,7 +285,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int e = threadIdx.x; e < 3 * E; e += blockDim.x) {
         float a = 0.f;
         for (int w = 0; w < wpb; w++) a += ln_smem[(size_t)w * 3 * E + e];
-        ws[(size_t)blockIdx.x * 3 * E + e] = a;
+        if (direct_g) {
+            // few workgroups (small batches): straight into the gradients, no second launch
+            if (e < E) atomicAdd(direct_g + e, a);
+            else if (e < 2 * E) atomicAdd(direct_b + (e - E), a);
+            else if (direct_cs) atomicAdd(direct_cs + (e - 2 * E), a);
+        } else {
+            ws[(size_t)blockIdx.x * 3 * E + e] = a;
+        }
     }
 }
 
@@ -636,12 +644,17 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
     DropCfg dcfg = make_drop(p_drop, seed, rng_stream);
     if (p_drop <= 0.f) dmask = nullptr;          // no mask: the consumer reads dx itself
     const int want_cs = colsum != nullptr;
-#define LN_BWD(TT, MI) layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E, (TT*)dmask, want_cs, dcfg)
+    // up to 256 workgroups (rows <= 2048) the per-workgroup partials go to the gradients by atomics from the kernel itself; beyond
+    // that (and always in deterministic mode) they are folded by ln_param_reduce_kernel
+    const bool direct = !deterministic && grid <= 256;
+    float* dg_ = direct ? dgamma : nullptr;
+#define LN_BWD(TT, MI) layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E, (TT*)dmask, want_cs, dcfg, dg_, dbeta, colsum)
     if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
     else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
 #undef LN_BWD
     KERNEL_CHECK();
-    ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), deterministic ? 1 : std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);
+    if (!direct)
+        ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), deterministic ? 1 : std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);
     KERNEL_CHECK();
     return CMP_OK;
 }
