@@ -555,3 +555,41 @@ def test_full_size_c5_decode():
     assert a.tolist() == b.tolist() and a.tolist() != c.tolist()
     assert len(set(a.tolist())) > 50
     m.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_training_learns_a_deterministic_sequence(dtype):
+    """End-to-end training dynamics (forward, backward, Keras Adam, dropout on): sequences in which the next id is a fixed function
+    of the current one are learnt -- the loss falls from ~ln(390) to well under 0.5 and next-token accuracy passes 95 % within 300
+    steps, in the parity mode and in the throughput mode alike, and the learnt model's greedy decode continues the sequence."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, T, B = 390, 128, 4, 2, 128, 16
+    m = Transformer(V, E, T, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, dtype=dtype, seed=3, max_batch=B, max_seq=T)
+    rng = np.random.default_rng(0)
+    nxt = lambda a: (a * 7 + 3) % V
+
+    def batch():
+        s = np.empty((B, T + 1), np.int64)
+        s[:, 0] = rng.integers(0, V, B)
+        for t in range(T):
+            s[:, t + 1] = nxt(s[:, t])
+        return s[:, :-1].astype(np.int32), s[:, 1:].astype(np.int32)
+    first = last = None
+    for step in range(300):
+        x, y = batch()
+        loss, acc = m.train_step(x, y, 2e-3)
+        assert np.isfinite(loss), step
+        if step == 0:
+            first = loss
+        last = (loss, acc)
+    assert first > 5.0 and last[0] < 0.5 and last[1] > 0.95, (first, last)
+    x, y = batch()
+    ev_loss, ev_acc = m.evaluate([(x, y)])
+    assert ev_loss < 0.3 and ev_acc > 0.97, (ev_loss, ev_acc)           # dropout off at evaluation
+    start = int(rng.integers(0, V))
+    want = [start]
+    for _ in range(20):
+        want.append(int(nxt(want[-1])))
+    got = m.generate(want[:4], 17, temperature=0.0, mode="kv").tolist()
+    assert got == want[4:], (got, want[4:])
+    m.close()
