@@ -37,6 +37,7 @@ _i, _f, _i64, _u64, _u32 = C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_uint32
 SIGNATURES = {
     "cmp_last_error": (C.c_char_p, []),
     "cmp_version": (_i, []),
+    "cmp_build_key": (C.c_char_p, []),
     "cmp_device_count": (_i, []),
     "cmp_ctx_create": (_i, [_i, C.POINTER(_P)]),
     "cmp_ctx_destroy": (_i, [_P]),
@@ -46,6 +47,7 @@ SIGNATURES = {
     "cmp_dp_init": (_i, [_P, _i, _i, _P]),
     "cmp_dp_allreduce_test": (_i, [_P, _P, _i]),
     "cmp_dp_set_gemm_cus": (_i, [_P, _i]),
+    "cmp_dp_set_mask_rank": (_i, [_P, _i]),
     "cmp_model_create": (_i, [_P, C.POINTER(ModelCfg), C.POINTER(_P)]),
     "cmp_model_destroy": (_i, [_P]),
     "cmp_param_count": (_i, [_P, C.POINTER(_i)]),
@@ -62,10 +64,13 @@ SIGNATURES = {
     "cmp_loss_and_grads": (_i, [_P, _P, _P, _i, _i, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_eval_step": (_i, [_P, _P, _P, _i, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)]),
     "cmp_present_get": (_i, [_P, _i, _i, _i, _P]),
+    "cmp_forward_generation": (_i, [_P, C.POINTER(_i64)]),
+    "cmp_present_get_at": (_i, [_P, _i, _i, _i, _i64, _P]),
     "cmp_forward_logits": (_i, [_P, _P, _i, _i, _P]),
     "cmp_forward": (_i, [_P, _P, _i, _i, _i, _P, _i, _P]),
     "cmp_decode_begin": (_i, [_P, _P, _i, _i, _f, _u64]),
     "cmp_decode_steps": (_i, [_P, _i, _P]),
+    "cmp_k_sample": (_i, [_P, _P, _i, _f, _u64, _u32, _i, _P]),
     "cmp_prof_begin": (_i, [_i]),
     "cmp_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "cmp_k_embed_fwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),

@@ -1,7 +1,7 @@
 """Builds composer_amd/lib/libcomposer_hip.so from composer_amd/csrc/*.hip with hipcc for gfx950.
 
 In-tree build (the .so travels to the GPU box with the repo snapshot).  Object files are cached under
-composer_amd/csrc/_obj keyed by the SHA-256 of (source, every header, compiler flags, hipcc version): an object is rebuilt
+composer_amd/csrc/_obj (untracked, key file beside each object so both always come from the same build) keyed by the SHA-256 of (source, every header, compiler flags, hipcc version): an object is rebuilt
 when that key changes, never by file time.  composer_amd/lib/BUILD_INFO.json records, per source, the key and whether this
 call compiled it or reused the cached object, plus the key the linked library was built from -- `verify()` (used by
 __graft_entry__.build and the ABI test) fails if the library on disk does not match the sources in the tree.
@@ -77,6 +77,26 @@ def _lib_key(keys):
     return hashlib.sha256("".join(keys).encode()).hexdigest()
 
 
+def _file_sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _key_object(lib_key, tag):
+    """A one-function object carrying the key the library is linked from: cmp_build_key() reads it back out of the .so itself,
+    so verify() checks the LIBRARY, not only the JSON beside it."""
+    src = os.path.join(OBJ, tag + "buildkey.cpp")
+    obj = os.path.join(OBJ, tag + "buildkey.o")
+    open(src, "w").write('extern "C" const char* cmp_build_key(void) { return "%s"; }\n' % lib_key)
+    r = subprocess.run(["g++", "-O1", "-fPIC", "-c", src, "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed for buildkey.cpp:\n" + r.stderr[-2000:])
+    return obj
+
+
 def build(force=False, verbose=True, asan=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -93,14 +113,16 @@ def build(force=False, verbose=True, asan=False):
         old = json.load(open(info_path))
     except Exception:
         pass
-    relink = any(c for _, c, _ in res) or not os.path.exists(lib) or old.get("library_key") != lib_key
+    relink = any(c for _, c, _ in res) or not os.path.exists(lib) or old.get("library_key") != lib_key \
+        or old.get("library_sha256") != _file_sha256(lib)
     if relink:
+        objs = objs + [_key_object(lib_key, tag)]
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + \
               ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"] + (["-fsanitize=address", "-shared-libsan"] if asan else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
-    info = {"library": os.path.basename(lib), "library_key": lib_key, "hipcc": _hipcc_version(), "arch": ARCH,
+    info = {"library": os.path.basename(lib), "library_key": lib_key, "library_sha256": _file_sha256(lib), "hipcc": _hipcc_version(), "arch": ARCH,
             "sources": {s: {"key": k, "compiled_by_this_call": bool(c)} for s, (_, c, k) in zip(SOURCES, res)},
             "relinked_by_this_call": bool(relink)}
     json.dump(info, open(info_path, "w"), indent=1)
@@ -119,7 +141,17 @@ def verify():
         return False
     if not os.path.exists(LIB):
         return False
-    return info.get("library_key") == _lib_key([source_key(s, FLAGS) for s in SOURCES])
+    want = _lib_key([source_key(s, FLAGS) for s in SOURCES])
+    if info.get("library_key") != want or info.get("library_sha256") != _file_sha256(LIB):
+        return False
+    # ... and the key linked INTO the library (a replaced or older .so next to a fresh BUILD_INFO.json fails here)
+    import ctypes
+    try:
+        fn = ctypes.CDLL(LIB).cmp_build_key
+    except (OSError, AttributeError):
+        return False
+    fn.restype = ctypes.c_char_p
+    return fn().decode() == want
 
 
 if __name__ == "__main__":

@@ -270,7 +270,9 @@ def evaluate(model_type, dataset_path, restoredir, use_generator, max_files):
 @click.option('--prompt-length', default=10, help='Number of events to take from the start of the prompt. Defaults to 10.')
 @click.option('--length', '-l', 'generate_length', default=1024, help='The length of the generated event sequence. Defaults to 1024')
 @click.option('--temperature', default=1.0, help='Sampling temperature; 0 = greedy argmax. Defaults to 1.0.')
-@click.option('--decode-mode', type=click.Choice(['reference-literal', 'kv-cache']), default='kv-cache')
+@click.option('--decode-mode', type=click.Choice(['reference-literal', 'kv-cache']), default=None,
+              help='kv-cache: model(x, past=presents); reference-literal: the reference\'s loop as written (no past). '
+                   'Default: kv-cache when prompt + length fits window_size, else reference-literal.')
 def generate(model_type, restoredir, output_filepath, prompt, prompt_ids, prompt_data, prompt_length, generate_length,
              temperature, decode_mode):
     """Generate a MIDI file (cli.py:617-680): MIDI prompt -> event ids -> model -> event ids -> MIDI.  An output path
@@ -292,15 +294,23 @@ def generate(model_type, restoredir, output_filepath, prompt, prompt_ids, prompt
         raise NotImplementedError()                              # cli.py:642-643
     x = x[:prompt_length]                                        # cli.py:649
     model.reset_states()
-    if decode_mode == 'kv-cache' and len(x) + generate_length - 1 > config.transformer.model.window_size:
-        # position ids would run past the wpe table (transformer.py:675-679,786).  The reference's own loop never feeds
-        # `past` back (cli.py:663-676), which is why it can emit any length: fall back to exactly that loop.
-        logging.warning('prompt ({}) + length ({}) - 1 exceeds window_size ({}): the KV-cache decode would index past the '
-                        'position table; using --decode-mode reference-literal (the reference\'s loop) instead. With the '
-                        'KV cache at most --length {} fits.'.format(
-                            len(x), generate_length, config.transformer.model.window_size,
-                            config.transformer.model.window_size - len(x) + 1))
-        decode_mode = 'reference-literal'
+    window = config.transformer.model.window_size
+    fits = len(x) + generate_length - 1 <= window
+    if decode_mode == 'kv-cache' and not fits:
+        # position ids would run past the wpe table (transformer.py:675-679,786): an explicit request cannot be honoured, and
+        # silently switching modes would change what is sampled (context-conditioned vs the reference's context-free loop)
+        raise click.UsageError('--decode-mode kv-cache: prompt ({}) + length ({}) - 1 exceeds window_size ({}); at most '
+                               '--length {} fits, or use --decode-mode reference-literal.'.format(
+                                   len(x), generate_length, window, window - len(x) + 1))
+    if decode_mode is None:
+        # no mode asked for: the KV cache when it fits; otherwise the reference's own loop, which never feeds `past` back
+        # (cli.py:663-676) and can therefore emit any length -- said on stderr whatever the log level
+        decode_mode = 'kv-cache' if fits else 'reference-literal'
+        if not fits:
+            click.echo('composer generate: prompt ({}) + length ({}) - 1 exceeds window_size ({}); using the reference\'s '
+                       'decode loop (--decode-mode reference-literal). With the KV cache at most --length {} fits.'.format(
+                           len(x), generate_length, window, window - len(x) + 1), err=True)
+    click.echo('decode-mode: {}'.format(decode_mode), err=True)
     ids = model.generate(x, generate_length, temperature=temperature, mode=decode_mode)
     all_ids = list(x) + ids.tolist()                             # prompt + generated (cli.py:676)
     out = Path(output_filepath)

@@ -603,24 +603,13 @@ __global__ void cache_fill2_kernel(const T* __restrict__ qkv, float* __restrict_
     vc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + 2 * E + e]);
 }
 
-// next id from logits[V] (argmax with lowest index on ties, or Gumbel-max), then the next input embedding
-__global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restrict__ logits, int ldz_row_off, int V,
-                                                          float temperature, unsigned seed, DecState* __restrict__ st,
-                                                          int32_t* __restrict__ ids, const float* __restrict__ wte,
-                                                          const float* __restrict__ wpe, float* __restrict__ x, int E,
-                                                          int first) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
+// The draw itself, shared by the per-token sampler and the kernel-level test entry (cmp_k_sample): every thread of a 256-thread
+// workgroup returns the chosen id.  temperature <= 0: argmax, lowest index on ties (tf.argmax).  Otherwise Gumbel-max:
+// argmax_c(z[c]/temperature + G_c), G_c = -log(-log(u_c)) with u_c a counter hash of (seed, draw counter, column) -- one
+// draw from softmax(z / temperature) (tf.random.categorical, cli.py:671-673).  bv/bi: 4-entry LDS scratch.
+__device__ __forceinline__ int sample_block(const float* __restrict__ z, int V, float temperature, unsigned seed, unsigned ctr,
+                                            float* bv, int* bi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* z = logits + ldz_row_off;
-    const unsigned ctr = st->rng;
-    const int pos0 = st->pos, adv = st->advance, nprod = st->produced, capI = st->cap, Wn = st->W;
-    int pos = first ? pos0 : (adv ? pos0 + 1 : 0);
-    const int posc = min(pos, Wn - 1);     // host refuses to step past the table; never index outside it
-    // the position row does not depend on the sampled id: requested now, consumed after the argmax
-    float pe[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const int e = tid + 256 * i; pe[i] = e < E ? wpe[(int64_t)posc * E + e] : 0.f; }
     float best = -INFINITY;
     int arg = 0x7fffffff;
     const float inv_t = temperature > 0.f ? 1.0f / temperature : 0.f;
@@ -653,7 +642,28 @@ __global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restric
 #pragma unroll
     for (int w = 1; w < 4; w++)
         if (bv[w] > fb || (bv[w] == fb && bi[w] < id)) { fb = bv[w]; id = bi[w]; }
-    id = min(max(id, 0), V - 1);         // all-NaN logits leave the sentinel index: never address outside wte
+    return min(max(id, 0), V - 1);       // all-NaN logits leave the sentinel index: never address outside wte
+}
+
+// next id from logits[V], then the next input embedding
+__global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restrict__ logits, int ldz_row_off, int V,
+                                                          float temperature, unsigned seed, DecState* __restrict__ st,
+                                                          int32_t* __restrict__ ids, const float* __restrict__ wte,
+                                                          const float* __restrict__ wpe, float* __restrict__ x, int E,
+                                                          int first) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int tid = threadIdx.x;
+    const float* z = logits + ldz_row_off;
+    const unsigned ctr = st->rng;
+    const int pos0 = st->pos, adv = st->advance, nprod = st->produced, capI = st->cap, Wn = st->W;
+    int pos = first ? pos0 : (adv ? pos0 + 1 : 0);
+    const int posc = min(pos, Wn - 1);     // host refuses to step past the table; never index outside it
+    // the position row does not depend on the sampled id: requested now, consumed after the argmax
+    float pe[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int e = tid + 256 * i; pe[i] = e < E ? wpe[(int64_t)posc * E + e] : 0.f; }
+    const int id = sample_block(z, V, temperature, seed, ctr, bv, bi);
     if (tid == 0) {
         if (nprod < capI) ids[nprod] = id;
         st->produced = nprod + 1;
@@ -664,6 +674,24 @@ __global__ __launch_bounds__(256) void dec_sample2_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; i++) { const int e = tid + 256 * i; if (e < E) x[e] = wte[(int64_t)id * E + e] + pe[i]; }
     for (int e = tid + 1024; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)posc * E + e];
+}
+
+// n independent draws from ONE logits row with counters counter0 .. counter0+n-1: the sampler of the decode chain exposed for
+// the distribution test against the oracle's softmax(z / temperature)
+__global__ __launch_bounds__(256) void sample_many_kernel(const float* __restrict__ z, int V, float temperature, unsigned seed,
+                                                          unsigned counter0, int32_t* __restrict__ ids) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int id = sample_block(z, V, temperature, seed, counter0 + blockIdx.x, bv, bi);
+    if (threadIdx.x == 0) ids[blockIdx.x] = id;
+}
+extern "C" int cmp_k_sample(void* stream, const float* logits, int V, float temperature, uint64_t seed, uint32_t counter0, int n,
+                            int32_t* ids_out) {
+    CMP_REQUIRE(logits && ids_out && V > 0 && n >= 0, "k_sample: bad arguments");
+    if (n == 0) return CMP_OK;
+    sample_many_kernel<<<n, 256, 0, (hipStream_t)stream>>>(logits, V, temperature, (unsigned)seed, counter0, ids_out);
+    KERNEL_CHECK();
+    return CMP_OK;
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ struct cmp_ctx {
     hipStream_t comm_stream = nullptr;  // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    uint32_t seed_mix = 0;              // mix32(rank), xor-ed into every dropout seed: replicas draw independent masks
     int gemm_max_wgs = 0;               // cap on the persistent GEMM grids while a communicator exists (0 = all CUs)
     hipStream_t copy_stream = nullptr;  // host -> device id uploads of the pipelined train loop
 };
@@ -112,11 +113,15 @@ struct cmp_model {
     int64_t next_ticket = 0;
     int64_t stage_cap = 0;             // tokens per staging buffer
     int lastB = 0, lastT = 0, last_past = 0;   // shape of the forward pass whose activations are held (cmp_present_get)
+    int64_t fwd_gen = 0;               // bumped by every forward pass (train steps and decode prefill included): a Presents
+                                       // object remembers the pass it came from and cmp_present_get_at refuses any other
     std::vector<hipEvent_t> bucket_ev; // L+2 events
     hipEvent_t comm_done = nullptr, metrics_ev = nullptr;
     DecodeState* dec = nullptr;
     int gemm_role = -1;                // profiler class of the GEMMs being enqueued (0 while the forward pass is)
 
+    // dropout seed of this replica: the model seed with the data-parallel rank folded in (rank 0: the seed itself)
+    uint64_t drop_seed() const { return (uint64_t)((uint32_t)cfg.seed ^ ctx->seed_mix); }
     const void* w(int64_t off) const { return dtype == CMP_BF16 ? (const void*)(S + off) : (const void*)(P + off); }
 };
 

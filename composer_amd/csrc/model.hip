@@ -166,6 +166,12 @@ extern "C" int cmp_dp_init(cmp_ctx* c, int rank, int nranks, const void* id128) 
     NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
     c->rank = rank;
     c->nranks = nranks;
+    c->seed_mix = mix32((uint32_t)rank);      // seed ^ mix32(rank): rank 0 keeps the model seed, the others draw their own masks
+    return CMP_OK;
+}
+extern "C" int cmp_dp_set_mask_rank(cmp_ctx* c, int rank) {
+    CMP_REQUIRE(c && rank >= 0, "dp_set_mask_rank: bad arguments");
+    c->seed_mix = mix32((uint32_t)rank);
     return CMP_OK;
 }
 extern "C" int cmp_dp_set_gemm_cus(cmp_ctx* c, int cus) {
@@ -440,7 +446,7 @@ __global__ void drop_apply_kernel(const T* __restrict__ in, T* __restrict__ out,
         out[i] = from_f32<T>(apply_drop(d, (uint32_t)(i / E), (uint32_t)(i % E), to_f32<T>(in[i])));
 }
 static int drop_apply(cmp_model* m, const void* in, void* out, int64_t n, float p, uint32_t stream_id) {
-    DropCfg d = make_drop(p, m->cfg.seed, stream_id);
+    DropCfg d = make_drop(p, m->drop_seed(), stream_id);
     int grid = (int)std::min<int64_t>(cdiv64(n, 256), 8192);
     if (m->dtype == CMP_BF16)
         drop_apply_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)in, (bf16_t*)out, n, m->cfg.embedding_size, d);
@@ -496,7 +502,7 @@ static int ln_bwd(cmp_model* m, const void* dy, const void* x, const float* gamm
                   const void* resid, void* dx, float* dgamma, float* dbeta, int rows, void* dmask, float* colsum, float p_drop,
                   uint32_t rng_stream) {
     return layernorm_bwd_run(m->ctx->stream, dy, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, m->ln_ws, rows, m->E, m->dtype,
-                             dmask, colsum, p_drop, m->cfg.seed, rng_stream, m->slab != nullptr);
+                             dmask, colsum, p_drop, m->drop_seed(), rng_stream, m->slab != nullptr);
 }
 
 static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
@@ -509,7 +515,7 @@ static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A
     ex.role = m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1);         // forward announces 0; backward: A^T = wgrad, else dgrad
     ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;              // leave CUs to the concurrent all-reduce kernels
     CHECK_RC(gemm_run(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
-                      out_fp32, splitk, p_drop, m->cfg.seed, rng_stream, flags, ex));
+                      out_fp32, splitk, p_drop, m->drop_seed(), rng_stream, flags, ex));
     if (det && colsum) CHECK_RC(colsum_det(m, C, ldc, colsum, M, N));
     return CMP_OK;
 }
@@ -554,7 +560,8 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
     const bool ln = m->cfg.use_layer_norm != 0;
     const int Tp = past_len, Tt = past_len + T;
     m->lastB = B; m->lastT = Tt; m->last_past = Tp;
-    CHECK_RC(cmp_k_embed_fwd(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, Tp, dt, pr, m->cfg.seed,
+    m->fwd_gen += 1;
+    CHECK_RC(cmp_k_embed_fwd(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, Tp, dt, pr, m->drop_seed(),
                              drop_stream(step, 0, 0)));
     CHECK_RC(refresh_transposed_weights(m));
     // Conv1D weight operand of the forward GEMMs: [in,out] as stored (fp32 mode), or the transposed bf16 copy (tb = 1)
@@ -569,7 +576,7 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         CHECK_RC(gemm(m, 0, wt, M, 3 * E, E, a.u, E, W(o.attn_w), wt ? E : 3 * E, Tp ? m->dqkv : a.qkv, 3 * E, m->P + o.attn_b, 0,
                       nullptr, 0, nullptr, 0, 0, 1, 0.f, 0));
         if (Tp) CHECK_RC(rows_copy(m, m->dqkv, a.qkv, B, T, 3 * E, T, 0, 3 * E, Tt, Tp, 3 * E));     // concat([past, new]) :423-426
-        CHECK_RC(cmp_k_attn_fwd(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, m->cfg.scale_attention, dt, pa, m->cfg.seed,
+        CHECK_RC(cmp_k_attn_fwd(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, m->cfg.scale_attention, dt, pa, m->drop_seed(),
                                 drop_stream(step, i, 1)));
         const void* att = a.att;
         if (Tp) { CHECK_RC(rows_copy(m, a.att, m->tmpE, B, T, E, Tt, Tp, E, T, 0, E)); att = m->tmpE; }
@@ -681,7 +688,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                       0));                                                         // datt
         const bool det = m->slab != nullptr;     // the fused bias sums are float atomics: a separate fixed-order pass instead
         CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
-                              dt, pa, m->cfg.seed, drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b));   // b_attn grad = column sums of dqkv
+                              dt, pa, m->drop_seed(), drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b));   // b_attn grad = column sums of dqkv
         if (det) CHECK_RC(colsum_det(m, m->dqkv, 3 * E, m->G + o.attn_b, M, 3 * E));
         CHECK_RC(gemm(m, 1, 0, E, 3 * E, M, a.u, E, m->dqkv, 3 * E, m->G + o.attn_w, 3 * E, nullptr, 0, nullptr, 0, nullptr, 0,
                       1, std::max(2, wgrad_splits(M, E, 3 * E)), 0.f, 0));
@@ -700,7 +707,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         }
         if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end));
     }
-    CHECK_RC(embed_bwd_run(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->cfg.seed,
+    CHECK_RC(embed_bwd_run(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->drop_seed(),
                            drop_stream(step, 0, 0), m->slab ? V : 0, (float*)m->slab, (size_t)m->slab_bytes));
     if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin));
     return CMP_OK;
@@ -817,14 +824,18 @@ static int upload_xy(cmp_model* m, const int32_t* x, const int32_t* y, int B, in
 static int ensure_stages(cmp_model* m, int64_t tokens) {
     if (m->stage_cap >= tokens) return CMP_OK;
     CMP_REQUIRE(m->stage_cap == 0, "train_step_async: staging was sized for %lld tokens", (long long)m->stage_cap);
+    // sized once for the whole workspace (every later batch fits); a failure part-way keeps what was allocated in the model
+    // (freed by cmp_model_destroy) and a retry only allocates what is still missing
     const int64_t cap = std::max<int64_t>(tokens, (int64_t)m->capB * m->capT);
-    HIP_CHECK(hipHostMalloc((void**)&m->stage_metrics, sizeof(Metrics) * cmp_model::STAGES, hipHostMallocDefault));
-    memset(m->stage_metrics, 0, sizeof(Metrics) * cmp_model::STAGES);
+    if (!m->stage_metrics) {
+        HIP_CHECK(hipHostMalloc((void**)&m->stage_metrics, sizeof(Metrics) * cmp_model::STAGES, hipHostMallocDefault));
+        memset(m->stage_metrics, 0, sizeof(Metrics) * cmp_model::STAGES);
+    }
     for (int i = 0; i < cmp_model::STAGES; i++) {
-        HIP_CHECK(hipHostMalloc((void**)&m->stage_host[i], (size_t)cap * 8, hipHostMallocDefault));
-        CHECK_RC(dev_alloc(m, &m->stage_dev[i], (size_t)cap * 8));
-        HIP_CHECK(hipEventCreateWithFlags(&m->stage_uploaded[i], hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&m->stage_done[i], hipEventDisableTiming));
+        if (!m->stage_host[i]) HIP_CHECK(hipHostMalloc((void**)&m->stage_host[i], (size_t)cap * 8, hipHostMallocDefault));
+        if (!m->stage_dev[i]) CHECK_RC(dev_alloc(m, &m->stage_dev[i], (size_t)cap * 8));
+        if (!m->stage_uploaded[i]) HIP_CHECK(hipEventCreateWithFlags(&m->stage_uploaded[i], hipEventDisableTiming));
+        if (!m->stage_done[i]) HIP_CHECK(hipEventCreateWithFlags(&m->stage_done[i], hipEventDisableTiming));
     }
     m->stage_cap = cap;
     return CMP_OK;
@@ -924,6 +935,19 @@ __global__ void present_gather_kernel(const T_* __restrict__ qkv, float* __restr
         const int kv = (int)(i / ((int64_t)D * T * H * B));
         out[i] = to_f32<T_>(qkv[((int64_t)b * T + t) * 3 * E + (1 + kv) * E + h * D + d]);
     }
+}
+extern "C" int cmp_forward_generation(cmp_model* m, int64_t* gen) {
+    CMP_REQUIRE(m && gen, "forward_generation: null argument");
+    *gen = m->fwd_gen;
+    return CMP_OK;
+}
+extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out);
+extern "C" int cmp_present_get_at(cmp_model* m, int layer, int B, int T, int64_t generation, float* host_out) {
+    CMP_REQUIRE(m, "present_get_at: null argument");
+    CMP_REQUIRE(generation == m->fwd_gen, "present_get_at: these presents belong to forward pass %lld, the activations held are those of "
+                "pass %lld (a later forward / train step / decode prefill overwrote them; read presents before the next pass)",
+                (long long)generation, (long long)m->fwd_gen);
+    return cmp_present_get(m, layer, B, T, host_out);
 }
 extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out) {
     CMP_REQUIRE(m && host_out, "present_get: null argument");

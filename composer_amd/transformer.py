@@ -39,8 +39,8 @@ class Presents:
     """Lazy `presents` tuple (transformer.py:797-806,820-821): L tensors [2,B,H,T,D] fetched from the saved
     c_attn activations only when indexed (the CLI never reads them)."""
 
-    def __init__(self, model, B, T):
-        self._m, self._B, self._T = model, B, T
+    def __init__(self, model, B, T, generation):
+        self._m, self._B, self._T, self._gen = model, B, T, generation
 
     def __len__(self):
         return self._m.decoder_layers_count
@@ -48,7 +48,7 @@ class Presents:
     def __getitem__(self, i):
         if not 0 <= i < len(self):
             raise IndexError(i)
-        return self._m._fetch_present(i, self._B, self._T)
+        return self._m._fetch_present(i, self._B, self._T, self._gen)
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -203,6 +203,10 @@ class Transformer:
             _lib.check(self._lib.cmp_dp_set_gemm_cus(self._ctx, int(gemm_cus)), 'cmp_dp_set_gemm_cus')
         self._dp = (int(rank), int(world_size))
 
+    def set_mask_rank(self, rank):
+        """Rank folded into the dropout seed (seed ^ mix32(rank)); init_data_parallel sets it to the communicator rank."""
+        _lib.check(self._lib.cmp_dp_set_mask_rank(self._ctx, int(rank)), 'cmp_dp_set_mask_rank')
+
     def all_reduce_sum(self, values):
         """Sum of a small float vector over the data-parallel ranks (RCCL, cmp_dp_allreduce_test)."""
         a = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
@@ -264,15 +268,18 @@ class Transformer:
         _lib.check(self._lib.cmp_forward(self._h, x.ctypes.data_as(C.c_void_p), B, T, past_len, past_ptrs, int(bool(training)),
                                          logits.ctypes.data_as(C.c_void_p)), 'cmp_forward')
         if use_cache is True:
-            return logits, Presents(self, B, past_len + T)
+            gen = C.c_int64()
+            _lib.check(self._lib.cmp_forward_generation(self._h, C.byref(gen)), 'cmp_forward_generation')
+            return logits, Presents(self, B, past_len + T, int(gen.value))
         return (logits,)
 
-    def _fetch_present(self, layer, B, T):
-        """presents[layer] = stack([key, value]) [2,B,H,T,D] of the forward pass that produced this Presents object
-        (valid until the next forward / train step of the model)."""
+    def _fetch_present(self, layer, B, T, generation):
+        """presents[layer] = stack([key, value]) [2,B,H,T,D] of the forward pass that produced this Presents object.  Valid
+        until the next forward / train step of the model: a read after that raises (never another pass's tensors)."""
         H = self.attention_head_count
         out = np.empty((2, B, H, T, self.embedding_size // H), np.float32)
-        _lib.check(self._lib.cmp_present_get(self._h, int(layer), B, T, out.ctypes.data_as(C.c_void_p)), 'cmp_present_get')
+        _lib.check(self._lib.cmp_present_get_at(self._h, int(layer), B, T, int(generation), out.ctypes.data_as(C.c_void_p)),
+                   'cmp_present_get_at')
         return out
 
     def train_step(self, x, y, learning_rate=None, sync=True):

@@ -65,6 +65,8 @@ typedef struct cmp_model_cfg {
 
 const char* cmp_last_error(void);
 int cmp_version(void);
+/* key (SHA-256 over sources, headers, flags, compiler) this library was linked from: composer_amd/build.py verify() */
+const char* cmp_build_key(void);
 /* number of visible HIP devices (0 when none); never initialises a device context beyond the count */
 int cmp_device_count(void);
 
@@ -82,6 +84,10 @@ int cmp_dp_allreduce_test(cmp_ctx* ctx, float* host_inout, int n);    /* sum ove
 /* While a communicator exists the persistent GEMM kernels launch at most `cus` workgroups (0 = all 256 CUs), leaving the
  * rest of the chip to the RCCL kernels of the overlapped gradient all-reduce.  Also settable with COMPOSER_DP_GEMM_CUS. */
 int cmp_dp_set_gemm_cus(cmp_ctx* ctx, int cus);
+/* Dropout masks are drawn from seed ^ mix32(rank) so that the replicas of a data-parallel job draw independent masks (the
+ * reference is single-device).  cmp_dp_init sets the rank of the communicator; this call overrides it (tests, or a
+ * launcher that shards without RCCL).  Parameter initialisation does NOT depend on it: replicas start identical. */
+int cmp_dp_set_mask_rank(cmp_ctx* ctx, int rank);
 
 /* ---- model: replaces models.Transformer(...) construction (cli.py:123-132) --------------------- */
 int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_model** out);
@@ -100,6 +106,8 @@ int cmp_adam_iter_set(cmp_model* m, int64_t iterations);
 
 /* ---- training: one iteration of the loop body at transformer.py:914-930 ------------------------
  * x, y: host int32 [B,T].  Forward (training=True) + sparse-CE + backward + (DP all-reduce) + Adam.
+ * Ids outside [0, V) fail the call before anything is enqueued; in a data-parallel job that is fatal for the whole job (the
+ * peer ranks are already waiting in the all-reduce): validate the dataset up front, abort every rank on an error.
  * loss/acc (host, may be NULL) are the batch mean loss and accuracy -- of this rank's shard, or, once cmp_dp_init has
  * run, the mean over all ranks (one 3-float all-reduce per step; the reference logs one loss per step, :929-939). */
 int cmp_train_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int T, float lr,
@@ -135,11 +143,21 @@ int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, cons
 /* presents[layer] of the LAST forward pass (Transformer.call's second result, transformer.py:797-806, 820-821):
  * host fp32 [2, B, H, T, D] = stack([key, value]) after split_heads.  B, T must be that pass's shape (T = past + new). */
 int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out);
+/* The activations a `presents` is read from live until the NEXT forward pass of the model (any of: cmp_forward*, a train or
+ * eval step, cmp_decode_begin's prefill).  cmp_forward_generation returns the id of the pass just run; cmp_present_get_at
+ * refuses (CMP_ERR_INVALID) when a later pass has replaced it -- the reference returns real tensors (transformer.py:820-821),
+ * so a stale read must be an error, never another pass's keys/values. */
+int cmp_forward_generation(cmp_model* m, int64_t* generation);
+int cmp_present_get_at(cmp_model* m, int layer, int B, int T, int64_t generation, float* host_out);
 
 /* ---- decode: the loop of cli.py:659-676 -------------------------------------------------------
  * temperature <= 0 => argmax with lowest-index tie-break (the tau->0 limit; cli.py:671 divides). */
 int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int mode, float temperature, uint64_t seed);
 int cmp_decode_steps(cmp_model* m, int n, int32_t* ids_out);
+/* The sampler of the decode chain on its own (dev pointers): n independent draws from ONE logits row [V] with draw counters
+ * counter0 .. counter0+n-1 -> ids_out[n].  tf.random.categorical(logits / temperature), cli.py:671-673. */
+int cmp_k_sample(void* stream, const float* logits, int V, float temperature, uint64_t seed, uint32_t counter0, int n,
+                 int32_t* ids_out);
 
 /* ---- live kernel timing (bench.py roofline): HIP events around every launch of ONE kernel class on the
  * stream it is launched on.  cls: 0 gemm forward (A[M,K].B[K,N]), 1 gemm dgrad (B stored [N,K]), 2 gemm wgrad

@@ -166,17 +166,39 @@ class Config:
         self.p_resid = residual_dropout_rate
 
 
-class OracleTransformer:
-    """Restatement of `Transformer` (transformer.py:599-960)."""
+def round_bf16(a):
+    """Round-to-nearest-even to bfloat16 precision (returned in the input's float type).  Used only by the
+    `emulate_bf16` mode below: the checker then rounds where the HIP bf16 kernels round."""
+    a = np.asarray(a)
+    f = np.ascontiguousarray(a, dtype=np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return u.view(np.float32).reshape(a.shape).astype(a.dtype if a.dtype.kind == "f" else np.float64)
 
-    def __init__(self, cfg, params, dtype=np.float64, seed=0):
+
+class OracleTransformer:
+    """Restatement of `Transformer` (transformer.py:599-960).
+
+    emulate_bf16=True keeps the reference's arithmetic but rounds to bfloat16 at the points where the HIP throughput
+    mode stores bf16 (activations written to HBM, the bf16 weight shadow feeding every GEMM, the
+    probabilities / score gradients feeding the attention MFMAs, the bf16 gradient tensors of the backward pass);
+    accumulation, LayerNorm statistics, softmax, logits and the loss stay in the oracle's float type.  It exists so
+    that the bf16 kernels can be held to a tolerance that reflects summation order only, not bf16 storage itself."""
+
+    def __init__(self, cfg, params, dtype=np.float64, seed=0, emulate_bf16=False):
         self.cfg = cfg
         self.dtype = dtype
+        self.emulate_bf16 = bool(emulate_bf16)
+        self.R = round_bf16 if emulate_bf16 else (lambda a: a)
         self.p = {k: np.array(v, dtype=dtype) for k, v in params.items()}
         self.m = {k: np.zeros_like(v) for k, v in self.p.items()}
         self.v = {k: np.zeros_like(v) for k, v in self.p.items()}
         self.iterations = 0          # Keras optimizer.iterations
         self.seed = seed
+
+    def _w(self, name):
+        """GEMM weight operand: the fp32 master value, or its bf16 shadow when emulating the throughput mode."""
+        return self.R(self.p[name])
 
     # ---------------------------------------------------------------- forward
     def _dropout(self, x, p, step, layer, site, training):
@@ -205,8 +227,10 @@ class OracleTransformer:
         pos = np.arange(past_len, T + past_len)                      # :770
         if pos.max() >= c.W:
             raise IndexError("position %d outside wpe table (%d rows)" % (pos.max(), c.W))
+        R, Wt = self.R, self._w
         h = P["wte/weight"][x] + P["wpe/embeddings"][pos][None]      # :137-138,786,793
         h, m_emb = self._dropout(h, c.p_resid, step, 0, 0, training)  # :794
+        h = R(h)
         cache = {"x": x, "pos": pos, "m_emb": m_emb, "layers": []}
         presents = []
         for i in range(c.L):
@@ -216,11 +240,12 @@ class OracleTransformer:
             # DecoderBlock.call :574-597 -- NOTE ln_1 output OVERWRITES the residual stream (:583-587)
             if c.use_ln:
                 u, lc["ln1"] = layernorm_fwd(x_in, P[pre + "ln_1/gamma"], P[pre + "ln_1/beta"], c.eps)
+                u = R(u)
             else:
                 u = x_in
             # Attention.call :397-448
-            qkv = u.reshape(-1, c.E) @ P[pre + "attn/c_attn/weight"] + P[pre + "attn/c_attn/bias"]  # :205-209
-            qkv = qkv.reshape(B, T, 3 * c.E)
+            qkv = u.reshape(-1, c.E) @ Wt(pre + "attn/c_attn/weight") + P[pre + "attn/c_attn/bias"]  # :205-209
+            qkv = R(qkv).reshape(B, T, 3 * c.E)
             q, k, v = np.split(qkv, 3, axis=2)                        # :417
             sh = lambda t: t.reshape(B, T, c.H, c.D).transpose(0, 2, 1, 3)   # :385-395
             q, k, v = sh(q), sh(k), sh(v)
@@ -235,31 +260,42 @@ class OracleTransformer:
             b = causal_mask(nd, ns, self.dtype)[None, None]
             w = w * b - 1e4 * (1 - b)                                 # :351-354
             w = w - w.max(-1, keepdims=True)
-            pr = np.exp(w)
-            pr = pr / pr.sum(-1, keepdims=True)                       # :360
+            pun = np.exp(w)
+            lsum = pun.sum(-1, keepdims=True)
+            pr = pun / lsum                                           # :360
             prd, m_att = self._dropout(pr, c.p_attn, step, i, 1, training)   # :361
-            a = prd @ v                                               # :367
+            if self.emulate_bf16:
+                # the kernel feeds the UNNORMALISED (masked) probabilities to the matrix cores in bf16 and applies
+                # keep-scale / row sum to the fp32 output
+                pm = pun if m_att is None else pun * (m_att > 0)
+                a = (R(pm) @ v) * ((1.0 / (1.0 - c.p_attn)) if m_att is not None else 1.0) / lsum
+                a = R(a)
+            else:
+                a = prd @ v                                           # :367
             a = a.transpose(0, 2, 1, 3).reshape(B, T, c.E)            # :373-383
-            ao = a.reshape(-1, c.E) @ P[pre + "attn/c_proj/weight"] + P[pre + "attn/c_proj/bias"]  # :443
+            ao = a.reshape(-1, c.E) @ Wt(pre + "attn/c_proj/weight") + P[pre + "attn/c_proj/bias"]  # :443
             ao = ao.reshape(B, T, c.E)
             ao, m_ao = self._dropout(ao, c.p_resid, step, i, 2, training)    # :444
-            r = u + ao                                                # :587
+            r = R(u + ao)                                             # :587
             if c.use_ln:
                 n, lc["ln2"] = layernorm_fwd(r, P[pre + "ln_2/gamma"], P[pre + "ln_2/beta"], c.eps)  # :591
+                n = R(n)
             else:
                 n = r
-            fc = n.reshape(-1, c.E) @ P[pre + "mlp/c_fc/weight"] + P[pre + "mlp/c_fc/bias"]      # :504
-            g = gelu(fc)
-            mo = g @ P[pre + "mlp/c_proj/weight"] + P[pre + "mlp/c_proj/bias"]                     # :505
+            fc = n.reshape(-1, c.E) @ Wt(pre + "mlp/c_fc/weight") + P[pre + "mlp/c_fc/bias"]      # :504
+            g = R(gelu(fc))
+            fc = R(fc)                                                # the stored pre-activation (backward only)
+            mo = g @ Wt(pre + "mlp/c_proj/weight") + P[pre + "mlp/c_proj/bias"]                    # :505
             mo = mo.reshape(B, T, c.E)
             mo, m_mo = self._dropout(mo, c.p_resid, step, i, 3, training)    # :506
-            h = r + mo                                                # :594
+            h = R(r + mo)                                             # :594
             if keep_cache:
                 lc.update(u=u, q=q, k=k, v=v, pr=pr, m_att=m_att, prd=prd, a=a, m_ao=m_ao, r=r, n=n,
                           fc=fc, g=g, m_mo=m_mo)
                 cache["layers"].append(lc)
         hf, lnf = layernorm_fwd(h, P["ln_f/gamma"], P["ln_f/beta"], c.eps)   # :811 (always applied)
-        logits = hf @ P["wte/weight"].T                               # :139-144,818
+        hf = R(hf)
+        logits = hf @ Wt("wte/weight").T                              # :139-144,818
         cache["hf"], cache["lnf"] = hf, lnf
         return logits, presents, cache
 
@@ -292,53 +328,72 @@ class OracleTransformer:
         dz = sm
         dz[np.arange(N), yy] -= 1.0
         dz /= N
+        R, Wt = self.R, self._w
+        dz = R(dz)
         G = {k: np.zeros_like(v) for k, v in P.items()}
         hf = cache["hf"].reshape(N, c.E)
         G["wte/weight"] += dz.T @ hf                                  # tied logits wgrad
-        dhf = (dz @ P["wte/weight"]).reshape(B, T, c.E)
+        dhf = R(dz @ Wt("wte/weight")).reshape(B, T, c.E)
         dh, G["ln_f/gamma"], G["ln_f/beta"] = layernorm_bwd(dhf, cache["lnf"], P["ln_f/gamma"])
+        dh = R(dh)
         sc = (1.0 / math.sqrt(c.D)) if c.scale else 1.0
         for i in reversed(range(c.L)):
             pre = "decoder_blocks/%d/" % i
             lc = cache["layers"][i]
             dx_out = dh
-            dmo = dx_out if lc["m_mo"] is None else dx_out * lc["m_mo"]
+            dmo = dx_out if lc["m_mo"] is None else R(dx_out * lc["m_mo"])
             dmo2 = dmo.reshape(N, c.E)
             G[pre + "mlp/c_proj/weight"] = lc["g"].T @ dmo2
             G[pre + "mlp/c_proj/bias"] = dmo2.sum(0, keepdims=True)
-            dg = dmo2 @ P[pre + "mlp/c_proj/weight"].T
+            dg = dmo2 @ Wt(pre + "mlp/c_proj/weight").T
             dfc = dg * gelu_grad(lc["fc"])
+            G[pre + "mlp/c_fc/bias"] = dfc.sum(0, keepdims=True)        # from the fp32 accumulators (fused column sums)
+            dfc = R(dfc)
             G[pre + "mlp/c_fc/weight"] = lc["n"].reshape(N, c.E).T @ dfc
-            G[pre + "mlp/c_fc/bias"] = dfc.sum(0, keepdims=True)
-            dn = (dfc @ P[pre + "mlp/c_fc/weight"].T).reshape(B, T, c.E)
+            dn = R(dfc @ Wt(pre + "mlp/c_fc/weight").T).reshape(B, T, c.E)
             if c.use_ln:
                 dln, G[pre + "ln_2/gamma"], G[pre + "ln_2/beta"] = layernorm_bwd(dn, lc["ln2"], P[pre + "ln_2/gamma"])
             else:
                 dln = dn
-            dr = dx_out + dln
-            dao = dr if lc["m_ao"] is None else dr * lc["m_ao"]
+            dr = R(dx_out + dln)
+            dao = dr if lc["m_ao"] is None else R(dr * lc["m_ao"])
             dao2 = dao.reshape(N, c.E)
             G[pre + "attn/c_proj/weight"] = lc["a"].reshape(N, c.E).T @ dao2
             G[pre + "attn/c_proj/bias"] = dao2.sum(0, keepdims=True)
-            da = (dao2 @ P[pre + "attn/c_proj/weight"].T).reshape(B, T, c.H, c.D).transpose(0, 2, 1, 3)
-            dv = lc["prd"].transpose(0, 1, 3, 2) @ da
+            da = R(dao2 @ Wt(pre + "attn/c_proj/weight").T).reshape(B, T, c.H, c.D).transpose(0, 2, 1, 3)
+            pr = lc["pr"]
             dprd = da @ lc["v"].transpose(0, 1, 3, 2)
             dpr = dprd if lc["m_att"] is None else dprd * lc["m_att"]
-            pr = lc["pr"]
-            dw = pr * (dpr - (dpr * pr).sum(-1, keepdims=True))
-            dw = dw * causal_mask(T, T, self.dtype)[None, None]       # d(w*b)
-            dq = sc * (dw @ lc["k"])
-            dk = sc * (dw.transpose(0, 1, 3, 2) @ lc["q"])
+            if self.emulate_bf16:
+                # the kernels recompute P in fp32 from the saved row statistics; delta = rowsum(dO * O) on the stored
+                # bf16 O; bf16 P (dropped, unscaled) feeds dV and bf16 dS feeds dQ / dK, keep-scale on the fp32 outputs
+                ks = (1.0 / (1.0 - c.p_attn)) if lc["m_att"] is not None else 1.0
+                keep = 1.0 if lc["m_att"] is None else (lc["m_att"] > 0)
+                o_bf = lc["a"].reshape(B, T, c.H, c.D).transpose(0, 2, 1, 3)
+                delta = (da * o_bf).sum(-1, keepdims=True)
+                dv = ks * (R(pr * keep).transpose(0, 1, 3, 2) @ da)
+                dw = pr * (dprd * keep - delta / ks) * causal_mask(T, T, self.dtype)[None, None]
+                dwb = R(dw)
+                dq = sc * ks * (dwb @ lc["k"])
+                dk = sc * ks * (dwb.transpose(0, 1, 3, 2) @ lc["q"])
+            else:
+                dv = lc["prd"].transpose(0, 1, 3, 2) @ da
+                dw = pr * (dpr - (dpr * pr).sum(-1, keepdims=True))
+                dw = dw * causal_mask(T, T, self.dtype)[None, None]   # d(w*b)
+                dq = sc * (dw @ lc["k"])
+                dk = sc * (dw.transpose(0, 1, 3, 2) @ lc["q"])
             mh = lambda t: t.transpose(0, 2, 1, 3).reshape(B, T, c.E)
             dqkv = np.concatenate([mh(dq), mh(dk), mh(dv)], axis=2).reshape(N, 3 * c.E)
+            G[pre + "attn/c_attn/bias"] = dqkv.sum(0, keepdims=True)    # from the fp32 accumulators
+            dqkv = R(dqkv)
             G[pre + "attn/c_attn/weight"] = lc["u"].reshape(N, c.E).T @ dqkv
-            G[pre + "attn/c_attn/bias"] = dqkv.sum(0, keepdims=True)
-            du = dr + (dqkv @ P[pre + "attn/c_attn/weight"].T).reshape(B, T, c.E)
+            du = R(dr + (dqkv @ Wt(pre + "attn/c_attn/weight").T).reshape(B, T, c.E))
             if c.use_ln:
                 dh, G[pre + "ln_1/gamma"], G[pre + "ln_1/beta"] = layernorm_bwd(du, lc["ln1"], P[pre + "ln_1/gamma"])
+                dh = R(dh)
             else:
                 dh = du
-        dh0 = dh if cache["m_emb"] is None else dh * cache["m_emb"]
+        dh0 = dh if cache["m_emb"] is None else dh * cache["m_emb"]       # masked in fp32 inside the scatter-add kernel
         np.add.at(G["wte/weight"], cache["x"].reshape(-1), dh0.reshape(N, c.E))   # gather grad
         G["wpe/embeddings"][cache["pos"]] += dh0.sum(0)
         return loss, acc, G, logits

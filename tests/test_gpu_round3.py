@@ -1,0 +1,226 @@
+"""-m gpu: the hot-path parity holes the round-2 review named.
+
+(a) temperature sampling (cli.py:670-673: tf.random.categorical(logits / temperature)): the product's Gumbel-max sampler
+    against the oracle's softmax(z / temperature) by chi-square -- at kernel level on one logits row with near-zero-probability
+    columns, and through the whole decode chain of BASELINE config 5's model;
+(b) data-parallel replicas draw different dropout masks (seed ^ mix32(rank)) from identical initial weights;
+(c) the bf16 throughput path against the oracle rounding to bf16 where the kernels round (emulate_bf16): a tolerance that
+    reflects summation order, not bf16 storage -- a dropped 1/(1-p) or a wrong mask on any dropout site is far outside it.
+"""
+import ctypes as C
+import numpy as np
+import pytest
+
+from oracle import transformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def chi_square_p(counts, probs, min_expected=8.0):
+    """Pearson chi-square of observed counts against expected probabilities; cells with a small expectation are pooled
+    (smallest first) until every cell expects >= min_expected draws.  Returns (p-value, degrees of freedom)."""
+    from scipy import stats
+    n = counts.sum()
+    exp = probs * n
+    order = np.argsort(exp)
+    e_cells, o_cells = [], []
+    acc_e = acc_o = 0.0
+    for i in order:
+        acc_e += exp[i]; acc_o += counts[i]
+        if acc_e >= min_expected:
+            e_cells.append(acc_e); o_cells.append(acc_o)
+            acc_e = acc_o = 0.0
+    if acc_e > 0:                      # leftover joins the last cell
+        e_cells[-1] += acc_e; o_cells[-1] += acc_o
+    e, o = np.array(e_cells), np.array(o_cells)
+    stat = ((o - e) ** 2 / e).sum()
+    dof = len(e) - 1
+    return float(stats.chi2.sf(stat, dof)), dof
+
+
+@pytest.mark.parametrize("temperature", [0.7, 1.0, 1.6])
+def test_sampler_distribution_matches_the_oracle_softmax(temperature):
+    """200 000 draws of the decode chain's sampler (cmp_k_sample = the code dec_sample2_kernel runs) from ONE row of V=390
+    logits: a few dominant columns, a broad middle, columns with probability ~1e-9 (never drawn) and exact ties."""
+    import torch
+    from composer_amd import _lib
+    lib = _lib.load(); _lib.require_gpu()
+    V, n = 390, 200_000
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal(V).astype(np.float32) * 1.5
+    z[[3, 77, 200]] += 4.0                      # dominant
+    z[[10, 11, 12, 389]] = -25.0                # near-zero probability
+    z[[20, 21]] = 0.5                           # exact tie
+    zd = torch.from_numpy(z).cuda()
+    ids = torch.empty(n, dtype=torch.int32, device="cuda")
+    rc = lib.cmp_k_sample(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(zd.data_ptr()), V, temperature, 123, 0,
+                          n, C.c_void_p(ids.data_ptr()))
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    got = ids.cpu().numpy()
+    assert got.min() >= 0 and got.max() < V
+    counts = np.bincount(got, minlength=V).astype(np.float64)
+    zz = z.astype(np.float64) / temperature                      # cli.py:671
+    p = np.exp(zz - zz.max()); p /= p.sum()                      # oracle._sample's distribution (cli.py:673)
+    assert counts[[10, 11, 12, 389]].sum() == 0                  # p ~ 1e-9 each
+    pv, dof = chi_square_p(counts, p)
+    assert dof > 100 and pv > 1e-3, (pv, dof)
+    # a wrong temperature is far outside the test's resolution: the same counts against softmax(z / (1.1 * temperature))
+    z2 = z.astype(np.float64) / (1.1 * temperature)
+    p2 = np.exp(z2 - z2.max()); p2 /= p2.sum()
+    assert chi_square_p(counts, p2)[0] < 1e-6
+    # same seed and counters reproduce the draws; other counters do not
+    ids2 = torch.empty(1000, dtype=torch.int32, device="cuda")
+    lib.cmp_k_sample(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(zd.data_ptr()), V, temperature, 123, 0, 1000,
+                     C.c_void_p(ids2.data_ptr()))
+    ids3 = torch.empty(1000, dtype=torch.int32, device="cuda")
+    lib.cmp_k_sample(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(zd.data_ptr()), V, temperature, 123, 1000, 1000,
+                     C.c_void_p(ids3.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(ids2.cpu().numpy(), got[:1000]) and np.array_equal(ids3.cpu().numpy(), got[1000:2000])
+
+
+def test_sampler_greedy_is_lowest_index_argmax():
+    import torch
+    from composer_amd import _lib
+    lib = _lib.load(); _lib.require_gpu()
+    V = 390
+    z = np.zeros(V, np.float32)
+    z[[40, 41, 300]] = 2.0                       # three-way tie: tf.argmax returns the lowest index
+    zd = torch.from_numpy(z).cuda()
+    ids = torch.empty(8, dtype=torch.int32, device="cuda")
+    rc = lib.cmp_k_sample(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(zd.data_ptr()), V, 0.0, 9, 0, 8,
+                          C.c_void_p(ids.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert ids.cpu().tolist() == [40] * 8
+
+
+def test_decode_chain_at_c5_samples_the_oracle_distribution():
+    """BASELINE config 5's model (6L/8H/d512) through the product decode chain (hipGraph-replayed per-token kernels) at
+    temperature 1.0.  In the reference's own loop (cli.py:663-676, `past` never fed back) every step after the first sees ONE
+    token at position 0, so the chain is a first-order Markov chain whose transition row for token a is
+    softmax(model([[a]]).logits / temperature): the pooled next-token histogram of 60 000 generated tokens is compared with
+    sum_a n_a * p_a (the oracle's rows) by chi-square, and the most visited row on its own as an exact multinomial."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W = 390, 512, 8, 6, 64
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=3, stddev=0.08).items()}
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="fp32", seed=0, max_batch=V, max_seq=8)
+    m.set_weights(params)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
+    rows = orc.forward(np.arange(V)[:, None])[0][:, 0, :]                  # [V(current token), V] logits at position 0
+    got_rows, _ = m(np.arange(V)[:, None])
+    assert np.abs(got_rows[:, 0, :] - rows).max() <= 1e-4                  # the product's own logits are the oracle's
+    P = np.exp(rows - rows.max(-1, keepdims=True)); P /= P.sum(-1, keepdims=True)
+    ent = float(-(P * np.log(P)).sum(-1).mean())
+    assert 2.0 < ent < 5.9, ent                                            # peaked enough to resolve a wrong temperature
+    n = 60_000
+    ids = m.generate([5], n, temperature=1.0, mode="literal", seed=11)
+    assert ids.min() >= 0 and ids.max() < V
+    cur, nxt = ids[:-1], ids[1:]
+    n_a = np.bincount(cur, minlength=V).astype(np.float64)
+    expect = n_a @ P
+    counts = np.bincount(nxt, minlength=V).astype(np.float64)
+    pv, dof = chi_square_p(counts, expect / expect.sum())
+    assert dof > 50 and pv > 1e-3, (pv, dof)
+    # resolution check: the same histogram against the rows at temperature 1.15 must be rejected
+    P2 = np.exp(rows / 1.15 - (rows / 1.15).max(-1, keepdims=True)); P2 /= P2.sum(-1, keepdims=True)
+    e2 = n_a @ P2
+    assert chi_square_p(counts, e2 / e2.sum())[0] < 1e-6
+    # the heaviest single transition row on its own (an exact multinomial)
+    a = int(np.argmax(n_a))
+    ca = np.bincount(nxt[cur == a], minlength=V).astype(np.float64)
+    if ca.sum() >= 2000:
+        assert chi_square_p(ca, P[a])[0] > 1e-3
+    m.close()
+
+
+def test_dp_ranks_draw_different_masks_from_identical_weights():
+    """dropout masks use seed ^ rank so replicas are independent; parameters start identical.  Two models built
+    with the same seed whose contexts carry mask rank 0 and 1: same weights, different training-mode logits, and each equals
+    the oracle drawing masks from ITS seed (rank 0: the seed; rank 1: seed ^ mix32(1))."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W, T, B = 390, 64, 4, 2, 48, 40, 2
+    x, _ = O.synthetic_batch(np.random.default_rng(3), V, B, T)
+    outs, weights = [], []
+    for rank in (0, 1):
+        m = Transformer(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, dtype="fp32", seed=77, max_batch=B, max_seq=W)
+        m.set_mask_rank(rank)
+        w = m.get_weights()
+        logits, _ = m(x, training=True)
+        mix = int(O._mix32(np.array([rank], dtype=np.uint64))[0])
+        orc = O.OracleTransformer(O.Config(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1),
+                                  {k: v.astype(np.float64) for k, v in w.items()}, seed=(77 ^ mix) & 0xFFFFFFFF)
+        want = orc.forward(x, training=True, step=0)[0]
+        assert np.abs(logits - want).max() <= 2e-4, rank
+        outs.append(logits); weights.append(w)
+        m.close()
+    for n in weights[0]:
+        assert np.array_equal(weights[0][n], weights[1][n]), n
+    assert np.abs(outs[0] - outs[1]).max() > 1e-2
+
+
+def test_stale_presents_are_refused():
+    """`_, p = m(x1); m(x2); p[0]` must raise: the activations p was to be read from now belong to another pass."""
+    from composer_amd.transformer import Transformer
+    from composer_amd import _lib
+    V, E, H, L, W = 390, 64, 4, 2, 32
+    m = Transformer(V, E, W, L, H, dtype="fp32", max_batch=1, max_seq=W)
+    x = np.arange(8)[None]
+    _, p1 = m(x)
+    k1 = p1[0].copy()
+    _, p2 = m(x + 1)
+    with pytest.raises(_lib.HipLibraryError):
+        p1[0]
+    assert p2[0].shape == k1.shape and not np.array_equal(p2[0], k1)
+    m.close()
+
+
+def _worst_rel(m, G):
+    from composer_amd import _lib
+    worst, name = 0.0, None
+    for n in m.parameter_names:
+        e = np.abs(m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64) - G[n]).max() / (np.abs(G[n]).max() + 1e-12)
+        if e > worst:
+            worst, name = e, n
+    return worst, name
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_bf16_small_model_against_the_bf16_emulating_oracle(p):
+    """Throughput-mode (bf16) loss and ALL gradients on a small model, dropout off and on, against the oracle that rounds to
+    bf16 at the kernels' storage points: <= 1.5e-2 of each gradient's largest element (the plain float64 oracle differs
+    from the same kernels by 3-8e-2 here)."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W, T, B = 390, 128, 4, 2, 160, 160, 2
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=21, stddev=0.05).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(8), V, B, T)
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p, dtype="bf16", seed=9, max_batch=B, max_seq=W)
+    m.set_weights(params)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p), params, seed=9, emulate_bf16=True)
+    loss, acc, G, _ = orc.loss_and_grads(x, y, training=True, step=0)
+    lb, _ = m.loss_and_grads(x, y)
+    assert abs(lb - loss) <= 2e-3 * loss, (lb, loss)
+    worst, name = _worst_rel(m, G)
+    assert worst <= 1.5e-2, (worst, name)
+    m.close()
+
+
+def test_bf16_c2_full_length_against_the_bf16_emulating_oracle():
+    """BASELINE config 2 (6L/8H/d512) on a FULL-LENGTH row (T=1024), the benchmark's dropout 0.1, bf16: loss <= 2e-3 relative and
+    every parameter gradient <= 2e-2 of its largest element against the bf16-emulating oracle with the same counter-hash masks
+    (round 2 held this path to 8e-2 against the float64 oracle)."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W, T = 390, 512, 8, 6, 1024, 1024
+    x, y = O.synthetic_batch(np.random.default_rng(78), V, 1, T)
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=0).items()}
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, dtype="bf16", seed=5, max_batch=1, max_seq=T)
+    m.set_weights(params)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1), params, seed=5,
+                              emulate_bf16=True)
+    loss, acc, G, _ = orc.loss_and_grads(x, y, training=True, step=0)
+    lb, _ = m.loss_and_grads(x, y)
+    assert abs(lb - loss) <= 2e-3 * loss, (lb, loss)
+    worst, name = _worst_rel(m, G)
+    assert worst <= 2e-2, (worst, name)
+    m.close()

@@ -153,3 +153,26 @@ def test_oracle_reproduces_golden(name):
     n = len(g["greedy_kv"])
     assert orc0.generate_kv(g["prompt"], n) == g["greedy_kv"].tolist()
     assert orc0.generate_literal(g["prompt"], n) == g["greedy_literal"].tolist()
+
+
+def test_bf16_emulation_rounds_to_nearest_even_and_keeps_the_formulas():
+    """round_bf16 against known values; the emulate_bf16 code path with rounding switched off reproduces the plain oracle's
+    loss and gradients (so the emulation differs from the reference's arithmetic by the roundings only)."""
+    r = O.round_bf16(np.array([1.0, 1.00390625, 1.01171875, -3.140625, 1e-30, 65504.0]))
+    assert r[0] == 1.0 and r[1] == 1.0 and r[2] == 1.015625 and r[3] == -3.140625 and r[5] == 65536.0
+    assert O.round_bf16(np.float32(1.005859375)) == np.float32(1.0078125)
+    V, E, H, L, W, T, B = 390, 32, 4, 2, 24, 20, 2
+    params = O.init_params(V, E, W, L, seed=4, stddev=0.2)
+    x, y = O.synthetic_batch(np.random.default_rng(1), V, B, T)
+    cfg = O.Config(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1)
+    a = O.OracleTransformer(cfg, params, seed=3)
+    b = O.OracleTransformer(cfg, params, seed=3, emulate_bf16=True)
+    b.R = lambda t: t
+    la, _, Ga, _ = a.loss_and_grads(x, y, training=True, step=2)
+    lb, _, Gb, _ = b.loss_and_grads(x, y, training=True, step=2)
+    assert abs(la - lb) < 1e-12
+    for k in Ga:
+        assert np.abs(Ga[k] - Gb[k]).max() <= 1e-12 * (np.abs(Ga[k]).max() + 1e-30), k
+    c = O.OracleTransformer(cfg, params, seed=3, emulate_bf16=True)
+    lc, _, Gc, _ = c.loss_and_grads(x, y, training=True, step=2)
+    assert 1e-6 < abs(lc - la) < 5e-2 * la
