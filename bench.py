@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--hog", default=None, help="measurement aid: 'WGS,USEC' -- before every step, WGS workgroups spin for USEC "
+                                               "microseconds on the communication stream (a stand-in for a concurrent RCCL kernel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -235,8 +237,8 @@ def main():
 
     Bq = args.batch or cf["B"]
     model = Transformer(V, E, W, L, H, attention_dropout_rate=args.dropout, residual_dropout_rate=args.dropout,
-                        dtype="bf16", seed=1000 + rank, max_batch=Bq, max_seq=T, device=local_rank)
-    model.initialize_parameters(0)                  # identical replicas
+                        dtype="bf16", seed=1000, max_batch=Bq, max_seq=T, device=local_rank)
+    model.initialize_parameters(0)                  # identical replicas; cmp_dp_init folds the rank into the dropout seed
     if under_launcher:      # every launched run (also 1 rank) takes the RCCL path: buckets, side stream, 1/N scale
         with stdout_to_stderr():
             uid = [Transformer.new_unique_id() if rank == 0 else None]
@@ -253,7 +255,11 @@ def main():
     ys = [torch.from_numpy(np.ascontiguousarray(mine[i, :, 1:])).to(dev) for i in range(n_data)]
     torch.cuda.synchronize()
 
+    hog = [int(v) for v in args.hog.split(",")] if args.hog else None
+
     def step(i):
+        if hog:
+            _lib.check(_lib.load().cmp_dp_test_hog(model._ctx, hog[0], hog[1]), "cmp_dp_test_hog")
         model.train_step_device(xs[i % n_data].data_ptr(), ys[i % n_data].data_ptr(), Bq, T, LR)
 
     def fence():

@@ -46,6 +46,7 @@ SIGNATURES = {
     "cmp_dp_unique_id": (_i, [_P]),
     "cmp_dp_init": (_i, [_P, _i, _i, _P]),
     "cmp_dp_allreduce_test": (_i, [_P, _P, _i]),
+    "cmp_dp_test_hog": (_i, [_P, _i, _i]),
     "cmp_dp_set_gemm_cus": (_i, [_P, _i]),
     "cmp_dp_set_mask_rank": (_i, [_P, _i]),
     "cmp_model_create": (_i, [_P, C.POINTER(ModelCfg), C.POINTER(_P)]),

@@ -1,1 +1,1 @@
-extern "C" const char* cmp_build_key(void) { return "832835f111dbfdf916f343089d7c077f9225c0ab2518ca891d0681a03a578ecc"; }
+extern "C" const char* cmp_build_key(void) { return "f680d856cbac083a421f544ecb71f4ac8b6d7d6e6bc1ba2be906bf7714c5e9a9"; }

@@ -30,6 +30,8 @@ struct Epilogue {
     int dbg_nostore;       // timing experiment only: run the whole epilogue but skip the global stores
     float* colsum;         // compile-time kinds only: out[col] += sum over rows of the STORED (rounded) C (f32 atomics)
     DropCfg drop;
+    uint32_t* sched;       // persistent kernels: item counters of this launch (ItemPuller below); null = static striding
+    uint32_t* sched_clear; // ... and the counter set the NEXT launch on this stream will draw from (zeroed by this one)
 };
 
 template <typename T, bool EXACT>
@@ -718,6 +720,110 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
 }
 
 // =================================================================================================
+// Item scheduling of the persistent kernels.  Items are dealt in eight groups (item & 7 = group = the label of the
+// workgroups that share an XCD under round-robin placement, item >> 3 = index inside the group; item_coords() maps a group
+// to a consecutive range of tiles so that an XCD's L2 serves one A row panel).  Round 2 strode statically
+// (next = item + gridDim.x): a workgroup that starts late, shares its CU with an RCCL kernel or is missing altogether
+// (CU cap) then keeps its whole share while the others idle.  Now every workgroup takes its FIRST item statically
+// (no latency in front of the first load) and CLAIMS each later one from its group's counter -- one returning atomic,
+// issued a whole item ahead of its use -- and steals from the other groups once its own is exhausted, so a slow
+// workgroup costs what it cannot do, not what it was assigned.  Eight counters on eight 128-byte lines; two counter
+// sets alternate between consecutive launches on a stream (a launch zeroes the set of the next one: no memset node).
+// Speed only: which workgroup runs an item never changes a result.
+// =================================================================================================
+#define SCHED_SET_WORDS (8 * 32 + 32 + 512)     // 8 group counters on their own 128-byte lines, `started`, 512 first-item flags
+struct ItemPuller {
+    uint32_t* ctr;          // this launch's counter set; null = static striding (a kernel argument: lives in SGPRs / the kernarg segment)
+    int nitems, grp;
+    uint32_t pending;       // thread 0: the counter value drawn by claim()
+    uint32_t first_old;     // thread 0: what the exchange on this workgroup's first-item flag returned (non-zero: stolen)
+    unsigned dead;          // thread 0: groups found exhausted
+    __device__ __forceinline__ int gcount(int x) const { return (nitems >> 3) + (x < (nitems & 7) ? 1 : 0); }
+    __device__ __forceinline__ int nstatic(int x) const { const int g = (int)gridDim.x; return x < g ? (g - x + 7) >> 3 : 0; }   // workgroups labelled x
+    __device__ __forceinline__ uint32_t* started() const { return ctr + 8 * 32; }
+    __device__ __forceinline__ uint32_t* taken() const { return ctr + 8 * 32 + 32; }
+    // Also takes this workgroup's own first item: an exchange on its flag, in flight while the item's first k-slab is
+    // loaded speculatively; first_was_stolen() is asked once that slab has landed.  A workgroup that got its CU late (the
+    // chip shared with an RCCL kernel) finds its item done by a workgroup that had run out of work.
+    __device__ __forceinline__ void init(const Epilogue& ep, int nitems_, int tid) {
+        ctr = ep.sched;
+        nitems = nitems_;
+        grp = blockIdx.x & 7;
+        pending = 0;
+        first_old = 0;
+        dead = 0;
+        if (ep.sched_clear && blockIdx.x == 0) {
+            for (int i = tid; i < SCHED_SET_WORDS; i += blockDim.x)
+                if (i >= 8 * 32 || (i & 31) == 0) __hip_atomic_store(ep.sched_clear + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (ctr && tid == 0) {
+            first_old = __hip_atomic_exchange(taken() + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(started(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // thread 0: draw the next index of the current group.  The value is first looked at a whole item later (claimed()), so
+    // the round trip hides under that item.  A compiler-counted atomic on purpose: its destination may be spilled or moved
+    // at once in the register-bound instantiations, which an inline-asm form would do BEFORE the value lands; beside the
+    // hand-counted LDS-DMA of the deep-pipeline kernel a compiler-sized wait can only be stronger than needed (operations
+    // the compiler cannot see are YOUNGER entries of the same in-order counter), never weaker.
+    __device__ __forceinline__ void claim(int tid) {
+        if (ctr && tid == 0) pending = __hip_atomic_fetch_add(ctr + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // thread 0, a whole item after claim(): the claimed item, or -1 when the group has run dry
+    __device__ __forceinline__ int claimed() {
+        const int idx = nstatic(grp) + (int)pending;
+        if (idx < gcount(grp)) return idx * 8 + grp;
+        dead |= 1u << grp;
+        return -1;
+    }
+    // WAVE 0 (all 64 lanes), BEFORE the epilogue of a workgroup whose own group has run dry: one wave-wide look at the eight
+    // group counters (lanes 0-7) and `started` (lane 8); the round trip hides under the epilogue, steal() consumes it.
+    __device__ __forceinline__ uint32_t peek(int lane) const {
+        uint32_t v = 0;
+        if (lane < 9) v = __hip_atomic_load(ctr + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    }
+    // WAVE 0 (all 64 lanes), after that epilogue -- only the end of a launch gets here: take an item from another group
+    // that peek() saw work in, else the first item of a workgroup that has not started yet.  Every lane returns the same
+    // value; in the common case (nothing left anywhere) no memory operation is issued here.
+    __device__ __forceinline__ int steal(int lane, uint32_t seen) {
+        const unsigned dd = (unsigned)__builtin_amdgcn_readfirstlane((int)dead);
+        const bool cand = lane < 8 && !((dd >> lane) & 1u) && (gcount(lane) - nstatic(lane)) > (int)seen;
+        unsigned m = (unsigned)__ballot(cand) & 0xFFu;
+        m = ((m >> grp) | (m << (8 - grp))) & 0xFFu;          // bit g: group (grp + g) & 7
+        while (m) {
+            const int g = __builtin_ctz(m);
+            m &= m - 1;
+            const int x = (grp + g) & 7;
+            const int left = gcount(x) - nstatic(x);
+            uint32_t c = 0xFFFFFFFFu;
+            if (lane == 0) c = __hip_atomic_fetch_add(ctr + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c < (uint32_t)left) return (nstatic(x) + (int)c) * 8 + x;
+            if (lane == 0) dead |= 1u << x;
+        }
+        const int g = (int)gridDim.x;
+        const int nstart = __builtin_amdgcn_readlane((int)seen, 8);
+        if (nstart >= g) return -1;
+        for (int base = 0; base < g; base += 64) {
+            const int w = base + lane;
+            const uint32_t f = w < g ? __hip_atomic_load(taken() + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+            unsigned long long mm = __ballot(f == 0u);
+            while (mm) {
+                const int bit = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                uint32_t old = 1u;
+                if (lane == 0) old = __hip_atomic_exchange(taken() + base + bit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane((int)old) == 0) return base + bit;      // that workgroup's static item
+            }
+        }
+        return -1;
+    }
+    // every thread, after a stolen item came back through the slot: later claims draw from that item's group
+    __device__ __forceinline__ void follow(int item) { grp = item & 7; }
+};
+
+// =================================================================================================
 // bf16 large-tile path: 256x256x64 workgroup tile, 8 waves (2 x 4) of 128x64, PERSISTENT workgroups (one per CU).
 //   * 128 FLOP per byte staged into LDS (the 128x128 tile: 64) -- the 128^2 kernel saturates L2->LDS bandwidth at
 //     ~1 PFLOP/s (measured on the K=2048 shapes);
@@ -805,6 +911,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
 
     int item = blockIdx.x;
     if (item >= nitems) return;
+    ItemPuller pl;
+    pl.init(ep, nitems, tid);
+    int* slot = reinterpret_cast<int*>(smem + 4 * H_IMG);      // the next item, published by thread 0
+    pl.claim(tid);                                             // the item after this one: in flight under the whole first item
     int m0, n0, kt0, kt1;
     item_coords(item, m0, n0, kt0, kt1);
     __amdgpu_buffer_rsrc_t ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
@@ -813,6 +923,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
         glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
     }
+    if (pl.ctr && tid == 0) slot[1] = (int)pl.first_old;
+    bool first = pl.ctr != nullptr;
     while (true) {
         f32x4 acc[8][4];
 #pragma unroll
@@ -820,8 +932,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();      // stage 0 of this item has landed (vmcnt(0) rides on the barrier); previous epilogue left stage 1
+        bool skip = false;    // this workgroup's first item was taken by another one before it got to run
+        if (first) {
+            first = false;
+            skip = __builtin_amdgcn_readfirstlane(slot[1]) != 0;
+            if (skip) {
+                if (tid == 0) *slot = pl.claimed();
+                __syncthreads();
+            }
+        }
         bf16x8 diag_a[2][2][4], diag_b[2][4];       // GEMM_DIAG 2 / 4 only
-        for (int kt = kt0; kt < kt1; kt++) {
+        for (int kt = kt0; kt < kt1 && !skip; kt++) {
             const int st = (kt - kt0) & 1;
             const char* ia = smem + st * 2 * H_IMG;
             const char* ib = ia + H_IMG;
@@ -871,13 +992,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                         }
                 }
             }
+            if (pl.ctr && kt == kt1 - 1 && tid == 0) *slot = pl.claimed();      // published by the barrier below
             __syncthreads();
         }
         // next item's first k-slab goes to stage 0 while this item's epilogue runs out of stage 1
         const int cm0 = m0, cn0 = n0;
-        const int next = item + gridDim.x;
-        const bool has_next = next < nitems;
+        int next = pl.ctr ? __builtin_amdgcn_readfirstlane(*slot) : (int)(item + gridDim.x < nitems ? item + gridDim.x : -1);
+        bool has_next = next >= 0;
         if (has_next) {
+            pl.claim(tid);
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
@@ -886,7 +1009,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                 glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
             }
         }
-        if (SWAP) {
+        uint32_t seen = 0;
+        if (!has_next && pl.ctr && wave == 0) seen = pl.peek(lane);
+        if (skip) {
+        } else if (SWAP) {
             float* stg = reinterpret_cast<float*>(smem + 2 * H_IMG) + wave * (16 * 68);   // stage 1: [16][68] floats per wave
             const int col = cn0 + wn * 64 + (lane & 7) * 8;
             if constexpr (EPI != EPI_GENERIC) {
@@ -933,7 +1059,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                     }
                 }
         }
-        if (!has_next) break;
+        if (!has_next) {
+            // own group exhausted: look at the other groups only now, behind this item's stores (a launch's tail)
+            if (!pl.ctr) break;
+            __syncthreads();                                   // every wave has read the slot and left the staging area
+            if (wave == 0) {
+                const int got = pl.steal(lane, seen);
+                if (lane == 0) *slot = got;
+            }
+            __syncthreads();
+            next = __builtin_amdgcn_readfirstlane(*slot);
+            if (next < 0) break;
+            pl.follow(next);
+            pl.claim(tid);
+            item_coords(next, m0, n0, kt0, kt1);
+            ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
+            rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
+            if (kt0 < kt1) {
+                glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
+                glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
+            }
+        }
         item = next;
     }
 }
@@ -1070,6 +1216,10 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
 
     int item = blockIdx.x;
     if (item >= nitems) return;
+    ItemPuller pl;
+    pl.init(ep, nitems, tid);
+    int* slot = reinterpret_cast<int*>(smem + NST * STAGE);   // the next item, published by thread 0
+    pl.claim(tid);             // OLDER than every DMA below: the counted vmcnt waits stay conservative
     int nstamp = 0;
     auto stamp = [&](int id) {
         if (DIAG && stamps && blockIdx.x == 17 && tid == 0 && nstamp < 250) {
@@ -1123,13 +1273,26 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
     for (int i = 0; i < AHEAD; i++)
         if (kt0 + i < kt1) issue(kt0 + i, i);
 
+    if (pl.ctr && tid == 0) slot[1] = (int)pl.first_old;
+    bool first = pl.ctr != nullptr;
     while (true) {
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int n = kt1 - kt0;
+        int n = kt1 - kt0;
+        bool skip = false;    // this workgroup's first item was taken by another one before it got to run
+        if (first) {
+            first = false;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            skip = __builtin_amdgcn_readfirstlane(slot[1]) != 0;
+            if (skip) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the speculative stages have landed: their buffers may be refilled
+                n = 0;
+            }
+        }
         // Software pipeline ACROSS the barrier: the wait+barrier that publishes stage t+1 sits inside stage t's 32
         // MFMAs and stage t+1's B fragments + first A fragment are read right after it, under the remaining MFMAs.
         bf16x8 fb[4], fa0;
@@ -1215,6 +1378,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             for (int t = 0; t < n; t++) run_stage(t, std::integral_constant<int, -1>());
         }
         stamp(20);
+        if (pl.ctr && tid == 0) *slot = pl.claimed();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave has finished reading the stages of this item
         stamp(21);
@@ -1222,9 +1386,10 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         // split-K with a slab workspace: every split writes its own fp32 partial tile with the ordinary full-line
         // epilogue (plain stores run ~4-5x the f32-atomic rate and the sum is reproducible); gemm_slab_reduce folds them
         void* Cit = slab_stride ? (void*)((float*)C + (int64_t)cur_split * slab_stride) : C;
-        const int next = item + gridDim.x;
-        const bool has_next = next < nitems;
+        int next = pl.ctr ? __builtin_amdgcn_readfirstlane(*slot) : (int)(item + gridDim.x < nitems ? item + gridDim.x : -1);
+        bool has_next = next >= 0;
         if (has_next) {
+            pl.claim(tid);                     // before the stage DMAs (older in the vmcnt queue)
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
@@ -1233,7 +1398,10 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                 if (kt0 + i < kt1) issue(kt0 + i, i);              // the epilogue owns the B image of the last stage
         }
         stamp(22);
-        if (SWAP) {
+        uint32_t seen = 0;
+        if (!has_next && pl.ctr && wave == 0) seen = pl.peek(lane);
+        if (skip) {
+        } else if (SWAP) {
             // per wave [16 rows][64 floats] = 4 KiB, 16-byte chunks xor-swizzled by the row
             float* stg = reinterpret_cast<float*>(smem + (NST - 1) * STAGE + A_IMG) + wave * (16 * 64);
             static_assert(NWAVES * 4096 <= B_IMG + (NWM == 2 ? A_IMG : 0), "epilogue staging must fit the last stage");
@@ -1287,7 +1455,28 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
                 }
         }
         stamp(30);
-        if (!has_next) break;
+        if (!has_next) {
+            // own group exhausted: look at the other groups only now, behind this item's stores (a launch's tail)
+            if (!pl.ctr) break;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave == 0) {
+                const int got = pl.steal(lane, seen);
+                if (lane == 0) *slot = got;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            next = __builtin_amdgcn_readfirstlane(*slot);
+            if (next < 0) break;
+            pl.follow(next);
+            pl.claim(tid);
+            item_coords(next, m0, n0, kt0, kt1);
+            ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
+            rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++)
+                if (kt0 + i < kt1) issue(kt0 + i, i);
+        }
         item = next;
         // the epilogue's stores/atomics sit in the same vmcnt queue behind the prefetched stages: drain them so the
         // counted waits of the next item see only its own DMA (the other workgroup on the CU keeps the pipes busy)
@@ -1315,7 +1504,7 @@ static bool launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const b
                           void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride, int max_wgs) {
     static bool attr_set = false;
     constexpr int BM = 128 * NWM;
-    const size_t smem = (size_t)NST * (BM * P_BK * 2 + 256 * P_BK * 2);
+    const size_t smem = (size_t)NST * (BM * P_BK * 2 + 256 * P_BK * 2) + 16;      // + the item slot
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1395,7 +1584,7 @@ template <bool A_KM, bool B_KM>
 static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
                        void* C, int ldc, const Epilogue& ep, int per, int nsplit, int tiles_n, int ntiles) {
     static bool attr_set = false;
-    const size_t smem = 4 * H_IMG;
+    const size_t smem = 4 * H_IMG + 16;                                             // + the item slot
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1431,6 +1620,35 @@ static void launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M,
 // =================================================================================================
 // host launcher
 // =================================================================================================
+// Item-counter workspace of the persistent kernels (ItemPuller): per stream, two sets of eight counters, one 128-byte line
+// each; `started` and one first-item flag per workgroup; consecutive launches on a stream alternate sets and every launch zeroes the other one.  COMPOSER_GEMM_STATIC=1
+// keeps the round-2 static striding (A/B timing).
+#include <mutex>
+#include <map>
+#define CHECK_SCHED(expr) do { int rc_ = (expr); if (rc_ != CMP_OK) return rc_; } while (0)
+struct SchedWs { uint32_t* dev = nullptr; int parity = 0; };
+static int sched_next(hipStream_t s, Epilogue& ep) {
+    static const bool is_static = [] { const char* e = getenv("COMPOSER_GEMM_STATIC"); return e && e[0] == '1'; }();
+    ep.sched = ep.sched_clear = nullptr;
+    if (is_static) return CMP_OK;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SchedWs> tab;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    SchedWs& w = tab[std::make_pair(dev, s)];
+    if (!w.dev) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return CMP_OK;   // static inside a capture
+        HIP_CHECK(hipMalloc((void**)&w.dev, 2 * SCHED_SET_WORDS * 4));
+        HIP_CHECK(hipMemset(w.dev, 0, 2 * SCHED_SET_WORDS * 4));
+    }
+    ep.sched = w.dev + w.parity * SCHED_SET_WORDS;
+    ep.sched_clear = w.dev + (w.parity ^ 1) * SCHED_SET_WORDS;
+    w.parity ^= 1;
+    return CMP_OK;
+}
+
 extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda,
                           const void* Bm, int ldb, void* C, int ldc, const float* bias, int act, void* aux, int ldaux,
                           const void* resid, int ldr, int out_fp32, int splitk, float p_drop, uint64_t seed,
@@ -1465,6 +1683,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
     ep.atomic = splitk > 1 ? 1 : 0;
     ep.dbg_nostore = (flags & 64) ? 1 : 0;
     ep.colsum = nullptr;
+    ep.sched = ep.sched_clear = nullptr;
     float* colsum_out = ex.colsum;
     if (colsum_out) CMP_REQUIRE(!out_fp32 && splitk <= 1, "gemm: column sums need a plain (non split-K) output in the compute dtype");
     bool colsum_fused = false;
@@ -1523,6 +1742,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             // split-K: partial slabs + reduce when the registered workspace is large enough, else f32 atomics
             const bool slabs = ep.atomic && nsplit > 1 && ldc == N && (N % 4 == 0) && g_slab_ws &&
                                (size_t)nsplit * M * N * 4 <= g_slab_bytes && !(flags & 128);
+            CHECK_SCHED(sched_next(s, ep));
             Epilogue ep2 = ep;
             if (slabs) ep2.atomic = 0;
             const bool swap = !ep2.atomic;
@@ -1543,6 +1763,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             const int g1 = std::min(ntiles * nsplit, max_wgs);
             const bool swap = !ep.atomic;
             ep.colsum = colsum_out;
+            CHECK_SCHED(sched_next(s, ep));
             if (!ta && !tb) colsum_fused = launch_256<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
             else if (!ta && tb) colsum_fused = launch_256<true, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
             else if (ta && !tb) colsum_fused = launch_256<false, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);

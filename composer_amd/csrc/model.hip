@@ -179,6 +179,25 @@ extern "C" int cmp_dp_set_gemm_cus(cmp_ctx* c, int cus) {
     c->gemm_max_wgs = cus;
     return CMP_OK;
 }
+// Measurement aid for the 1-GPU box: what a concurrent RCCL kernel does to the compute stream, without a second GPU.  `wgs`
+// workgroups of 1024 threads and 64 KiB of LDS each (a persistent GEMM workgroup cannot share their CU) spin for `usec`
+// microseconds on the communication stream (highest priority) -- tools/ab_sched.sh times train steps beside it.
+__global__ __launch_bounds__(1024) void cu_hog_kernel(unsigned long long ticks, int* sink) {
+    __shared__ int big[16384];
+    big[threadIdx.x] = (int)threadIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (big[(threadIdx.x * 7) & 16383] == -1) *sink = 1;
+}
+extern "C" int cmp_dp_test_hog(cmp_ctx* c, int wgs, int usec) {
+    CMP_REQUIRE(c && wgs > 0 && wgs <= 256 && usec > 0 && usec <= 1000000, "dp_test_hog: bad arguments");
+    static int* sink = nullptr;
+    if (!sink) HIP_CHECK(hipMalloc((void**)&sink, 16));
+    cu_hog_kernel<<<wgs, 1024, 0, c->comm_stream>>>((unsigned long long)usec * 100ull, sink);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
 extern "C" int cmp_dp_allreduce_test(cmp_ctx* c, float* host_inout, int n) {
     CMP_REQUIRE(c && c->comm, "dp_allreduce_test: communicator not initialised");
     float* d = nullptr;

@@ -81,6 +81,9 @@ void* cmp_ctx_stream(cmp_ctx* ctx);
 int cmp_dp_unique_id(void* id128);                                   /* rank 0: fills 128 bytes */
 int cmp_dp_init(cmp_ctx* ctx, int rank, int nranks, const void* id128);
 int cmp_dp_allreduce_test(cmp_ctx* ctx, float* host_inout, int n);    /* sum over ranks, for tests */
+/* measurement aid: `wgs` workgroups that no persistent GEMM workgroup can share a CU with spin for `usec` microseconds on the
+ * communication stream -- a stand-in for a concurrent RCCL kernel on a 1-GPU box (tools/ab_sched.sh) */
+int cmp_dp_test_hog(cmp_ctx* ctx, int wgs, int usec);
 /* While a communicator exists the persistent GEMM kernels launch at most `cus` workgroups (0 = all 256 CUs), leaving the
  * rest of the chip to the RCCL kernels of the overlapped gradient all-reduce.  Also settable with COMPOSER_DP_GEMM_CUS. */
 int cmp_dp_set_gemm_cus(cmp_ctx* ctx, int cus);

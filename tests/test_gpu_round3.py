@@ -224,3 +224,29 @@ def test_bf16_c2_full_length_against_the_bf16_emulating_oracle():
     worst, name = _worst_rel(m, G)
     assert worst <= 2e-2, (worst, name)
     m.close()
+
+
+def test_item_stealing_beside_a_cu_hog_keeps_the_results():
+    """The persistent GEMM kernels hand items out dynamically (per-XCD counters, stealing, late workgroups' first items taken by
+    idle ones).  While 96 workgroups that no GEMM workgroup can share a CU with hold a third of the chip (cmp_dp_test_hog on the
+    communication stream: what an RCCL kernel does), bf16 train steps at a size that takes the persistent kernels give the
+    losses of the undisturbed run -- which workgroup computes a tile never changes it."""
+    from composer_amd.transformer import Transformer
+    from composer_amd import _lib
+    V, E, H, L, W, T, B = 390, 256, 4, 2, 256, 256, 32
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=2).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(9), V, B, T)
+    curves = []
+    for hog in (False, True, True):
+        m = Transformer(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, dtype="bf16", seed=4, max_batch=B, max_seq=W)
+        m.set_weights(params)
+        losses = []
+        for s in range(4):
+            if hog:
+                _lib.check(m._lib.cmp_dp_test_hog(m._ctx, 96, 3000), "cmp_dp_test_hog")
+            losses.append(m.train_step(x, y, 1e-3)[0])
+        m.synchronize()
+        curves.append(losses)
+        m.close()
+    for c in curves[1:]:
+        assert np.allclose(c, curves[0], rtol=2e-4, atol=0), (c, curves[0])
