@@ -1,1 +1,1 @@
-extern "C" const char* cmp_build_key(void) { return "f680d856cbac083a421f544ecb71f4ac8b6d7d6e6bc1ba2be906bf7714c5e9a9"; }
+extern "C" const char* cmp_build_key(void) { return "4155e28bae357178bab751d9838f32fc3a0a6f75818d079f811e4819cd56636f"; }

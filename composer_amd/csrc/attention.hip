@@ -608,6 +608,262 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
 }
 
 // =================================================================================================
+// forward, bf16 / D = 64, second structure ("fwd64").  What round 2 measured on the kernel above: no pipe is busy (matrix
+// 25 %, vector ~30-50 %, LDS 33 %) -- the waves wait: for the register-staged K/V loads (-26 % without them), for the
+// staging stores and for a barrier every 16 MFMAs.  Here
+//   * a wave owns 64 query rows (two 32-row blocks), so a staged 64-key tile feeds 32 MFMAs per wave between barriers and
+//     every K / V fragment read from LDS is used twice;
+//   * K and V tiles reach LDS by LDS-DMA (buffer_load ... lds, issued from inline asm so that hipcc's wait-count pass
+//     never sees a pending LDS write) into a 3-stage ring: two tiles in flight behind counted s_waitcnt vmcnt, no staging
+//     registers, no staging stores, ONE raw s_barrier per tile;
+//   * the LDS images are lane-linear (what the DMA writes), 128-byte rows; the bank-conflict swizzles sit on the per-lane
+//     SOURCE address and on the read address: K (ds_read_b128 by rows) 16-byte chunk ^ ((row >> 1) & 7), V
+//     (ds_read_b64_tr_b16) 64-byte half ^ ((row >> 1) & 1);
+//   * 256 threads, 2 workgroups per CU (256 registers per wave, 48 KiB of LDS each): two independent workgroups per SIMD
+//     interleave matrix and vector work.
+// A workgroup takes a PAIR of 256-row query blocks (heaviest with lightest, as above); inside a block wave w owns the
+// 32-row blocks w and 7-w.  Tiles below the block are mask-free; the (up to four) tiles on the diagonal are masked by
+// comparison in every wave (masked probabilities are exactly 0), which keeps every accumulating MFMA out of branches.
+// =================================================================================================
+typedef int a2_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char a2_lds_char;
+__device__ __forceinline__ a2_v4i a2_make_srd(const void* base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    a2_v4i d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xFFFFu));
+    d[2] = __builtin_amdgcn_readfirstlane((int)min(bytes, (int64_t)0x7FFFFFF0));
+    d[3] = 0x00020000;
+    return d;
+}
+// one 1-KiB LDS-DMA piece: LDS [lds_addr, +1024) <- 16 bytes per lane from base + voff + soff (range-checked: zeros past the end)
+__device__ __forceinline__ void a2_dma16(a2_v4i srd, uint32_t lds_addr, int voff, int soff) {
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+#pragma unroll
+    for (int i = 0; i < 4; i++) srd[i] = __builtin_amdgcn_readfirstlane(srd[i]);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+                 : "memory", "m0");
+}
+#define A2_STAGES 3
+#define A2_IMG 8192                 // one [64 keys][64 d] bf16 image
+// A2_DIAG (measurement builds only -- results are wrong; tools/attn_ab.sh): 1 no exponentials, 2 no softmax arithmetic at all,
+// 3 no DMA inside the tile loop, 4 no barrier / counted waits, 5 no PV MFMAs, 6 no score MFMAs, 8 one workgroup per CU
+#ifndef A2_DIAG
+#define A2_DIAG 0
+#endif
+#if A2_DIAG == 8
+#define A2_MINW 1
+#else
+#define A2_MINW 2
+#endif
+#define A2_STAGE (2 * A2_IMG)
+
+template <bool DROP>
+__global__ __launch_bounds__(256, A2_MINW) void attn_fwd64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int Tn, int H, float scale, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    xcd_block(bx, by, H);
+    const int b = by / H, hd = by % H;
+    const int E = H * 64;
+    const int64_t rs = 3 * E;
+    const bf16_t* qg = qkv + (int64_t)b * Tn * rs + hd * 64;
+    bf16_t* og = o + (int64_t)b * Tn * E + hd * 64;
+    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const int nb = cdiv(Tn, 256);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(a2_lds_char*)smem_raw;
+    const int64_t span = ((int64_t)(Tn - 1) * rs + 64) * 2;
+    const a2_v4i srk = a2_make_srd(qg + E, span), srv = a2_make_srd(qg + 2 * E, span);
+    const int rsb = (int)(rs * 2);                                       // row stride in bytes
+    // this wave's DMA pieces: pieces 2w, 2w+1 of the K image and of the V image (8 rows x 128 B each)
+    int kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), pc = lane & 7;
+        kvo[i] = row * rsb + ((pc ^ ((row >> 1) & 7)) << 4);
+        vvo[i] = row * rsb + ((pc ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    auto issue = [&](int t, int stage) {
+        const int soff = t * 64 * rsb;
+        const uint32_t kb = lds0 + stage * A2_STAGE + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srk, kb + i * 1024, kvo[i], soff);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srv, kb + A2_IMG + i * 1024, vvo[i], soff);
+    };
+    // fragment read addresses (byte offsets inside an image)
+    int koff[4];                                                        // K rows: lane = key row, chunk 2s + h
+#pragma unroll
+    for (int s = 0; s < 4; s++) koff[s] = (lane & 31) * 128 + (((2 * s + h) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int G = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    int voffr[2];                                                       // V transposed reads: dt = 0, 1
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) voffr[dt] = (4 * (G >> 1) + qq) * 128 + ((dt ^ ((qq >> 1) & 1)) << 6) + 32 * (G & 1) + 8 * pp;
+
+    for (int ph = 0; ph < 2; ph++) {
+        const int hi = nb - 1 - bx;
+        const int qb = ph == 0 ? hi : (bx < hi ? bx : -1);
+        if (qb < 0) break;
+        int q0[2] = {qb * 256 + 32 * wave, qb * 256 + 32 * (7 - wave)};
+        int q[2];
+        bool qvalid[2];
+        bf16x8 qf[2][4];
+        uint32_t rowh[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            q[i] = q0[i] + (lane & 31);
+            qvalid[i] = q[i] < Tn;
+            load_bfrags<bf16_t, 64>(qf[i], qg, rs, q[i], qvalid[i], h);
+            rowh[i] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q[i]));
+        }
+        f32x16 oacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc[i][dt][r] = 0.f;
+        float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+        const int kv_end = min(Tn, qb * 256 + 256);
+        const int nt = cdiv(kv_end, 64), nint = qb * 4;                  // tiles; the first nint lie below every query row of the block
+        issue(0, 0);
+        if (nt > 1) issue(1, 1);
+
+        // one 64-key tile for both 32-row blocks of this wave; MASK (compile time): compare keys with queries / Tn
+        auto tile = [&](auto MASKT, const int t, const int st) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(MASKT)::value;
+            const char* Ks = smem_raw + st * A2_STAGE;
+            const char* Vs = Ks + A2_IMG;
+            bf16x8 kf[2][4];
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) kf[sub][s] = *reinterpret_cast<const bf16x8*>(Ks + sub * 4096 + koff[s]);
+            f32x16 sc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sc[i][sub][r] = 0.f;
+#pragma unroll
+#if A2_DIAG == 6
+                    for (int r = 0; r < 16; r++) sc[i][sub][r] = (float)kf[sub][r & 3][r & 7] * 1e-3f + (float)(t + r);
+#else
+                    for (int s = 0; s < 4; s++) sc[i][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][s], qf[i][s], sc[i][sub], 0, 0, 0);
+#endif
+                }
+            bf16x8 pb[2][2][2];                                          // [block][sub][k-step]: probabilities as the B operand
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (MASK) {
+#pragma unroll
+                    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int key = t * 64 + 32 * sub + rho(r, h);
+                            if (key > q[i] || key >= Tn) sc[i][sub][r] = neg_big;      // == -1e4 after scaling (transformer.py:354)
+                        }
+                }
+#if A2_DIAG == 2
+                if (false) {
+#else
+                {
+#endif
+                const float mloc = half_max(fmaxf(max16(sc[i][0]), max16(sc[i][1])));
+                const float mnew = fmaxf(m[i], mloc);
+                if (!__all(mnew == m[i])) {
+                    const float alpha = fast_exp2((m[i] - mnew) * c2);
+                    lsum[i] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) oacc[i][dt][r] *= alpha;
+                    m[i] = mnew;
+                }
+                const float mc = m[i] * c2;
+                f32x2 ps = {0.f, 0.f};
+#if A2_DIAG == 1
+#pragma unroll
+                for (int r = 0; r < 16; r++) { sc[i][0][r] = fmaf(sc[i][0][r], c2, -mc); sc[i][1][r] = fmaf(sc[i][1][r], c2, -mc); ps[0] += sc[i][0][r]; ps[1] += sc[i][1][r]; }
+#else
+                ps = exp2_scaled16(sc[i][0], c2, -mc, ps);
+                ps = exp2_scaled16(sc[i][1], c2, -mc, ps);
+#endif
+                lsum[i] += ps[0] + ps[1];
+                }
+                if constexpr (DROP) {
+                    mask16_qlane<true>(sc[i][0], rowh[i], t * 64, h, drop.thr);
+                    mask16_qlane<true>(sc[i][1], rowh[i], t * 64 + 32, h, drop.thr);
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) pb[i][sub][s][j] = (bf16_t)sc[i][sub][8 * s + j];
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++) {
+                        const char* va = Vs + (32 * sub + 16 * s) * 128 + voffr[dt];
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va));
+                        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 8 * 128));
+                        bf16x8 a;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { a[j] = lo[j]; a[4 + j] = hi4[j]; }
+#pragma unroll
+                        for (int i = 0; i < 2; i++) {
+#if A2_DIAG == 5
+                            asm volatile("" ::"v"(a), "v"(pb[i][sub][s]));
+                            oacc[i][dt][(sub * 2 + s) & 15] += 1.0f;
+#else
+                            oacc[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[i][sub][s], oacc[i][dt], 0, 0, 0);
+#endif
+                        }
+                    }
+        };
+        auto step = [&](auto MASKT, const int t) __attribute__((always_inline)) {
+            // tile t has landed: this wave's pieces by the counted wait (tile t+1's four may still fly), the others' by the barrier;
+            // past the barrier every wave has left tile t-1, whose stage takes tile t+2
+#if A2_DIAG != 4
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+#if A2_DIAG != 3
+            if (t + 2 < nt) issue(t + 2, (t + 2) % A2_STAGES);
+#endif
+            tile(MASKT, t, t % A2_STAGES);
+        };
+        int t = 0;
+        for (; t < nint; t++) step(std::false_type{}, t);
+        for (; t < nt; t++) step(std::true_type{}, t);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float ltot = half_sum(lsum[i]);
+            const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q[i], qvalid[i], dt, oacc[i][dt], inv, h);
+            if (qvalid[i] && h == 0) lse[(int64_t)by * Tn + q[i]] = m[i] * scale + logf(ltot);
+        }
+        // the second block's first tiles go into stages the slower waves may still be reading
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// =================================================================================================
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
 // With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
 // =================================================================================================
@@ -910,8 +1166,38 @@ static int attn_grid_x(int Tn, int BH) {
     const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2;
     return (nb > 1 && (int64_t)pairs * BH < 512) ? nb : pairs;
 }
+// COMPOSER_ATTN64=force (read per call) takes the 64-rows-per-wave LDS-DMA forward kernel below (tests/test_gpu_attn64.py runs
+// every shape through it).  It is NOT the default: measured on one box at the C2 shape (B*H = 1024, T = 1024), 289 us without
+// dropout against 264-300 for the kernel above, and 528 us with dropout (its mask arithmetic pushes the 64-row state past 256
+// registers: scratch traffic inside a loop that counts vmcnt by hand) -- DESIGN.md "Attention, round 3".
+static int attn64_mode() {
+    const char* e = getenv("COMPOSER_ATTN64");
+    if (!e) return 0;
+    return e[0] == 'o' ? -1 : (e[0] == 'f' ? 1 : 0);
+}
 template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
+    if constexpr (std::is_same<T, bf16_t>::value && D == 64) {
+        const int nb = cdiv(Tn, 256), pairs = (nb + 1) / 2;
+        const int mode = attn64_mode();
+        if (mode > 0 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
+            const size_t smem2 = A2_STAGES * A2_STAGE;
+            static bool attr = false;
+            if (!attr) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+                attr = true;
+            }
+            dim3 grid(pairs, B * H);
+            const double flops = 2.0 * B * H * (double)Tn * Tn * D;
+            PROF_START(3, s);
+            if (d.thr) attn_fwd64_kernel<true><<<grid, 256, smem2, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            else attn_fwd64_kernel<false><<<grid, 256, smem2, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            PROF_STOP(3, s, flops);
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+    }
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem > 65536) {
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -13,7 +13,7 @@ def main():
     B.build(verbose=False)
     obj = os.path.join(B.OBJ, "ab_%s_%s" % (name, src.replace(".hip", ".o")))
     subprocess.run([B._hipcc()] + B.FLAGS + extra + ["-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
-    objs = [obj if s == src else os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B.SOURCES]
+    objs = [obj if s == src else os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B.SOURCES] + [os.path.join(B.OBJ, "buildkey.o")]
     out = os.path.join(B.LIBDIR, name + ".so")
     subprocess.run([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs +
                    ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"], check=True)

@@ -113,6 +113,16 @@ def bench_gemm():
     print("sum of the 12 per-layer GEMMs: %.1f us  (%.1f TFLOP/s average)" % (tot, 3 * 2.0 * M * 12 * E * E / tot / 1e6))
 
 
+def bench_attn_fwd():
+    qkv = rnd(M, 3 * E)
+    o = torch.zeros(M, E, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(B * H * T, device="cuda")
+    fl = 2.0 * B * H * T * T * D
+    for p in (0.0, 0.1):
+        us = min(timeit(lambda: lib.cmp_k_attn_fwd(st(), P(qkv), P(o), P(lse), B, T, H, D, 1, BF16, p, 1, 2)) for _ in range(3))
+        print("attn fwd  p=%.1f  %8.1f us  %7.1f TFLOP/s (causal-half flops)" % (p, us, fl / us / 1e6))
+
+
 def bench_attn():
     qkv = rnd(M, 3 * E)
     o = torch.zeros(M, E, device="cuda", dtype=torch.bfloat16)
@@ -167,5 +177,7 @@ if __name__ == "__main__":
         bench_wgrad_diag()
     if "attn" in what:
         bench_attn()
+    if "attnfwd" in what:
+        bench_attn_fwd()
     if "ln" in what:
         bench_ln()
