@@ -15,8 +15,10 @@ with fp32 master weights/accumulation, dropout 0.1 (default_config.yml:39-40), A
 Inputs are generated up front and live in HBM before the timed region.
 
 One JSON line on rank 0 with `roofline` (live HIP-event timing of the dominant kernel class inside the timed
-region), `cpu_baseline` (the CPU restatement of the reference path on the host cores, bounded sample; N=1 only) and
-`decode` (BASELINE config 5, with its own memory roofline).
+region), `cpu_baseline` (the CPU restatement of the reference path on the host cores, bounded sample; N=1 only),
+`decode` (BASELINE config 5, with its own memory roofline) and, at N=1, three more driver-timed objects: `classes` (the live
+roofline of EVERY kernel class of the step, three extra steps each), `b32` (SURVEY's C2 batch, 32 sequences) and `c4` (BASELINE
+config 4), each `{ms_per_step, value, model_mfma_frac}` from 3 warm-up + 10 timed steps.
 """
 import argparse
 import ctypes as C
@@ -180,6 +182,36 @@ def decode_bench(device):
                          "note": "fp32 weights %.1f MB + mean K/V cache read %.2f MB per token" % (weight_bytes / 1e6, kv_bytes / 1e6)}}
 
 
+def side_config(name, Bq, device, dropout, steps=10, warmup=3):
+    """A short timed run of another configuration on the same GPU (N=1): 3 warm-up + 10 steps, inputs resident in HBM."""
+    import torch
+    from composer_amd.transformer import Transformer
+    cf = CONFIGS[name]
+    E, H, L, T = cf["E"], cf["H"], cf["L"], cf["T"]
+    m = Transformer(V, E, T, L, H, attention_dropout_rate=dropout, residual_dropout_rate=dropout, dtype="bf16", seed=1000,
+                    max_batch=Bq, max_seq=T, device=device)
+    m.initialize_parameters(0)
+    rng = np.random.default_rng(4321)
+    seq = rng.integers(0, V, size=(2, Bq, T + 1), dtype=np.int32)
+    dev = torch.device("cuda", device)
+    xs = [torch.from_numpy(np.ascontiguousarray(seq[i, :, :-1])).to(dev) for i in range(2)]
+    ys = [torch.from_numpy(np.ascontiguousarray(seq[i, :, 1:])).to(dev) for i in range(2)]
+    for i in range(warmup):
+        m.train_step_device(xs[i % 2].data_ptr(), ys[i % 2].data_ptr(), Bq, T, LR)
+    m.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        m.train_step_device(xs[i % 2].data_ptr(), ys[i % 2].data_ptr(), Bq, T, LR)
+    m.synchronize()
+    dt = time.perf_counter() - t0
+    loss, _ = m.last_metrics()
+    m.close()
+    value = Bq * T * steps / dt
+    return {"workload": "%s, seq=%d, B=%d, dropout %.2f" % (cf["label"], T, Bq, dropout), "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps, "value": value, "unit": "tokens/s",
+            "model_mfma_frac": value * flops_per_token_train(E, L, T) / 1e12 / PEAK_BF16_TFLOPS, "final_loss": loss}
+
+
 def self_launch(args):
     """--gpus N>1 without a launcher: run N ranks of this file under torch.distributed.run as a CHILD process (this parent
     has not touched the GPU), forward their stdout/stderr, return the launcher's exit status."""
@@ -203,6 +235,7 @@ def main():
     ap.add_argument("--roofline-kernel", type=int, default=0, help="kernel class timed live (see KERNEL_CLASSES)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-class roofline table and the b32 / c4 side runs")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--hog", default=None, help="measurement aid: 'WGS,USEC' -- before every step, WGS workgroups spin for USEC "
                                                "microseconds on the communication stream (a stand-in for a concurrent RCCL kernel)")
@@ -281,6 +314,24 @@ def main():
     ms, n_launch, work = C.c_double(), C.c_int64(), C.c_double()
     lib.cmp_prof_end(C.byref(ms), C.byref(n_launch), C.byref(work))
     loss, acc = model.last_metrics()
+    # the live roofline of every kernel class of the step (outside the timed region: three more steps per class)
+    classes = None
+    if world == 1 and not args.no_extras:
+        classes = []
+        for cls in sorted(KERNEL_CLASSES):
+            lib.cmp_prof_begin(cls)
+            for i in range(3):
+                step(i)
+            cms, cn, cw = C.c_double(), C.c_int64(), C.c_double()
+            lib.cmp_prof_end(C.byref(cms), C.byref(cn), C.byref(cw))
+            if cn.value > 0 and cms.value > 0:
+                nm, bound = KERNEL_CLASSES[cls]
+                rate = cw.value / (cms.value * 1e-3)
+                peak = PEAK_BF16_TFLOPS * 1e12 if bound == "mfma" else PEAK_HBM_GBS * 1e9
+                classes.append({"kernel": nm.split(" (")[0], "bound": bound, "launches_per_step": cn.value // 3,
+                                "avg_us": 1e3 * cms.value / cn.value, "ms_per_step": cms.value / 3,
+                                "achieved": rate / (1e12 if bound == "mfma" else 1e9), "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                                "frac": rate / peak})
     if dist.is_initialized():
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -326,8 +377,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cf)
         else:
             out["cpu_baseline"] = None
+        if classes is not None:
+            out["classes"] = classes
     model.close()
     if rank == 0:
+        if world == 1 and not args.no_extras:
+            if not (args.config == "c2" and Bq == 32):
+                out["b32"] = side_config("c2", 32, local_rank, args.dropout)
+            if args.config != "c4":
+                out["c4"] = side_config("c4", CONFIGS["c4"]["B"], local_rank, args.dropout)
         if world == 1 and not args.no_decode:
             out["decode"] = decode_bench(local_rank)
         print(json.dumps(out), flush=True)

@@ -4,8 +4,8 @@
 # 1-rank communicator with and without the CU cap.
 out=gpurun_out/${1:-r3b}
 mkdir -p $out
-b() { python bench.py --no-cpu-baseline --no-decode --steps 20 --warmup 5 "$@" 2>>$out/err.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(round(d['ms_per_step'],3))"; }
-dp() { python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-decode --steps 20 --warmup 5 2>>$out/err.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(round(d['ms_per_step'],3))"; }
+b() { python bench.py --no-cpu-baseline --no-decode --no-extras --steps 20 --warmup 5 "$@" 2>>$out/err.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(round(d['ms_per_step'],3))"; }
+dp() { python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-decode --no-extras --steps 20 --warmup 5 2>>$out/err.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(round(d['ms_per_step'],3))"; }
 {
 for i in 1 2; do
   echo "plain          dynamic $(b)   static $(COMPOSER_GEMM_STATIC=1 b)"

@@ -7,7 +7,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 print("%-96s %8s %9s %10s %7s" % ("kernel class (bench.py --config %s --roofline-kernel n)" % cfg, "launches", "avg us", "achieved", "frac"))
 for cls in range(8):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--roofline-kernel", str(cls), "--no-cpu-baseline",
-                        "--no-decode", "--steps", "10", "--warmup", "3"], capture_output=True, text=True)
+                        "--no-decode", "--no-extras", "--steps", "10", "--warmup", "3"], capture_output=True, text=True)
     try:
         d = json.loads(r.stdout.strip().split("\n")[-1])
         rf = d["roofline"]
