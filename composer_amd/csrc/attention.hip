@@ -647,7 +647,9 @@ __device__ __forceinline__ void a2_dma16(a2_v4i srd, uint32_t lds_addr, int voff
                  : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
                  : "memory", "m0");
 }
-#define A2_STAGES 3
+#ifndef A2_STAGES
+#define A2_STAGES 3                 // ring stages: A2_STAGES - 1 tiles in flight
+#endif
 #define A2_IMG 8192                 // one [64 keys][64 d] bf16 image
 // A2_DIAG (measurement builds only -- results are wrong; tools/attn_ab.sh): 1 no exponentials, 2 no softmax arithmetic at all,
 // 3 no DMA inside the tile loop, 4 no barrier / counted waits, 5 no PV MFMAs, 6 no score MFMAs, 8 one workgroup per CU
@@ -731,8 +733,9 @@ __global__ __launch_bounds__(256, A2_MINW) void attn_fwd64_kernel(const bf16_t* 
         float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
         const int kv_end = min(Tn, qb * 256 + 256);
         const int nt = cdiv(kv_end, 64), nint = qb * 4;                  // tiles; the first nint lie below every query row of the block
-        issue(0, 0);
-        if (nt > 1) issue(1, 1);
+#pragma unroll
+        for (int i = 0; i < A2_STAGES - 1; i++)
+            if (i < nt) issue(i, i);
 
         // one 64-key tile for both 32-row blocks of this wave; MASK (compile time): compare keys with queries / Tn
         auto tile = [&](auto MASKT, const int t, const int st) __attribute__((always_inline)) {
@@ -832,17 +835,21 @@ __global__ __launch_bounds__(256, A2_MINW) void attn_fwd64_kernel(const bf16_t* 
                     }
         };
         auto step = [&](auto MASKT, const int t) __attribute__((always_inline)) {
-            // tile t has landed: this wave's pieces by the counted wait (tile t+1's four may still fly), the others' by the barrier;
-            // past the barrier every wave has left tile t-1, whose stage takes tile t+2
+            // tile t has landed: this wave's pieces by the counted wait (the younger tiles' pieces may still fly), the others' by the
+            // barrier; past the barrier every wave has left tile t-1, whose stage takes tile t + A2_STAGES - 1
 #if A2_DIAG != 4
-            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                const int ahead = min(nt - 1 - t, A2_STAGES - 2);       // younger tiles that may stay in flight (4 pieces each)
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
 #if A2_DIAG != 3
-            if (t + 2 < nt) issue(t + 2, (t + 2) % A2_STAGES);
+            if (t + A2_STAGES - 1 < nt) issue(t + A2_STAGES - 1, (t + A2_STAGES - 1) % A2_STAGES);
 #endif
             tile(MASKT, t, t % A2_STAGES);
         };
