@@ -1,1 +1,1 @@
-extern "C" const char* cmp_build_key(void) { return "89cfaa4aa28e89a3e257a06429174215543ed4aa6ee7c9802a0b9735a22e21d5"; }
+extern "C" const char* cmp_build_key(void) { return "65bd30286900208e8261b28e4328bc4ab265d8edd42654d5ab0132e92d0e817d"; }

@@ -1636,10 +1636,12 @@ static int sched_next(hipStream_t s, Epilogue& ep) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
+    // inside a stream capture the launch is replayed with frozen arguments: the alternation of the two counter sets would not
+    // survive a replay, so captured launches stride statically
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return CMP_OK;
     SchedWs& w = tab[std::make_pair(dev, s)];
     if (!w.dev) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return CMP_OK;   // static inside a capture
         HIP_CHECK(hipMalloc((void**)&w.dev, 2 * SCHED_SET_WORDS * 4));
         HIP_CHECK(hipMemset(w.dev, 0, 2 * SCHED_SET_WORDS * 4));
     }
