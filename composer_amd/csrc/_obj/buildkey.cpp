@@ -1,1 +1,1 @@
-extern "C" const char* cmp_build_key(void) { return "65bd30286900208e8261b28e4328bc4ab265d8edd42654d5ab0132e92d0e817d"; }
+extern "C" const char* cmp_build_key(void) { return "f821bbb4f913d4535cce7c12464e4ad4c2cc1bb9249f4771ca424554dddc2700"; }

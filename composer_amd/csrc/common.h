@@ -59,6 +59,7 @@ struct GemmExtra {
     size_t slab_bytes = 0;
     int role = -1;               // cmp_prof_* timing class: 0 forward, 1 dgrad, 2 wgrad, -1 = by operand layout
     int max_wgs = 0;             // cap on the persistent kernels' grid (CUs left to a concurrent RCCL kernel); 0 = all 256
+    bool dp = false;             // the launch belongs to a data-parallel job: persistent kernels hand their items out dynamically
 };
 int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* Bm, int ldb,
              void* C, int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,

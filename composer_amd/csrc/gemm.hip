@@ -732,50 +732,60 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
 // Speed only: which workgroup runs an item never changes a result.
 // =================================================================================================
 #define SCHED_SET_WORDS (8 * 32 + 32 + 512)     // 8 group counters on their own 128-byte lines, `started`, 512 first-item flags
+// Only wave-uniform values live in the struct; what thread 0 draws (the pending claim, the answer of the exchange on its own
+// first-item flag, the set of exhausted groups) is PARKED IN LDS (slot[1..3]) before the k-loop starts: a single vector
+// register kept alive across that loop, or one LDS write inside it, changed hipcc's schedule of the fragment reads and cost
+// the forward / dgrad GEMMs 10-30 % (same-box A/B against the round-2 kernel).
+// slot[0] (256-kernel: slot[0] / slot[4] alternately) next item   slot[1] own first-item flag as found (non-zero: taken by another
+// workgroup)   slot[2] parked claim (deep-pipeline kernel) / stolen item   slot[3] exhausted groups
 struct ItemPuller {
-    uint32_t* ctr;          // this launch's counter set; null = static striding (a kernel argument: lives in SGPRs / the kernarg segment)
+    uint32_t* ctr;          // this launch's counter set; null = static striding
     int nitems, grp;
-    uint32_t pending;       // thread 0: the counter value drawn by claim()
-    uint32_t first_old;     // thread 0: what the exchange on this workgroup's first-item flag returned (non-zero: stolen)
-    unsigned dead;          // thread 0: groups found exhausted
     __device__ __forceinline__ int gcount(int x) const { return (nitems >> 3) + (x < (nitems & 7) ? 1 : 0); }
     __device__ __forceinline__ int nstatic(int x) const { const int g = (int)gridDim.x; return x < g ? (g - x + 7) >> 3 : 0; }   // workgroups labelled x
     __device__ __forceinline__ uint32_t* started() const { return ctr + 8 * 32; }
     __device__ __forceinline__ uint32_t* taken() const { return ctr + 8 * 32 + 32; }
-    // Also takes this workgroup's own first item: an exchange on its flag, in flight while the item's first k-slab is
-    // loaded speculatively; first_was_stolen() is asked once that slab has landed.  A workgroup that got its CU late (the
-    // chip shared with an RCCL kernel) finds its item done by a workgroup that had run out of work.
     __device__ __forceinline__ void init(const Epilogue& ep, int nitems_, int tid) {
         ctr = ep.sched;
         nitems = nitems_;
         grp = blockIdx.x & 7;
-        pending = 0;
-        first_old = 0;
-        dead = 0;
         if (ep.sched_clear && blockIdx.x == 0) {
             for (int i = tid; i < SCHED_SET_WORDS; i += blockDim.x)
                 if (i >= 8 * 32 || (i & 31) == 0) __hip_atomic_store(ep.sched_clear + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    // thread 0, kernel start, BEFORE the first loads: take this workgroup's own first item (an exchange on its flag, in flight
+    // while the item's first k-slab is loaded speculatively -- a workgroup that got its CU late, the chip shared with an RCCL
+    // kernel, finds its item done by a workgroup that had run out of work), count it as started, and claim the item after.
+    __device__ __forceinline__ void start(int tid, uint32_t& first_old, uint32_t& pend) {
+        first_old = 0;
+        pend = 0;
         if (ctr && tid == 0) {
             first_old = __hip_atomic_exchange(taken() + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(started(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend = __hip_atomic_fetch_add(ctr + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // thread 0: draw the next index of the current group.  The value is first looked at a whole item later (claimed()), so
-    // the round trip hides under that item.  A compiler-counted atomic on purpose: its destination may be spilled or moved
-    // at once in the register-bound instantiations, which an inline-asm form would do BEFORE the value lands; beside the
-    // hand-counted LDS-DMA of the deep-pipeline kernel a compiler-sized wait can only be stronger than needed (operations
-    // the compiler cannot see are YOUNGER entries of the same in-order counter), never weaker.
-    __device__ __forceinline__ void claim(int tid) {
-        if (ctr && tid == 0) pending = __hip_atomic_fetch_add(ctr + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // thread 0: draw the next index of the current group (the value is looked at a whole item later).  A compiler-counted
+    // atomic on purpose: beside the hand-counted LDS-DMA of the deep-pipeline kernel a compiler-sized wait can only be stronger
+    // than needed (operations the compiler cannot see are YOUNGER entries of the same in-order counter), never weaker.
+    __device__ __forceinline__ uint32_t claim(int tid) const {
+        uint32_t pend = 0x7FFFFFFFu;                                   // (a group whose items are all first items has nothing to claim)
+        if (ctr && tid == 0)
+            pend = __hip_atomic_fetch_add(ctr + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return pend;
     }
-    // thread 0, a whole item after claim(): the claimed item, or -1 when the group has run dry
-    __device__ __forceinline__ int claimed() {
-        const int idx = nstatic(grp) + (int)pending;
-        if (idx < gcount(grp)) return idx * 8 + grp;
-        dead |= 1u << grp;
+    // thread 0: the item a claim stands for, or -1 when the group has run dry
+    __device__ __forceinline__ int resolve(uint32_t pend, int* slot) const {
+        if (pend < 0x7FFFFFFFu) {
+            const int idx = nstatic(grp) + (int)pend;
+            if (idx < gcount(grp)) return idx * 8 + grp;
+        }
+        slot[3] |= 1 << grp;
         return -1;
     }
+    // thread 0: the item the parked claim stands for, or -1 when the group has run dry
+    __device__ __forceinline__ int claimed(int* slot) const { return resolve((uint32_t)slot[2], slot); }
     // WAVE 0 (all 64 lanes), BEFORE the epilogue of a workgroup whose own group has run dry: one wave-wide look at the eight
     // group counters (lanes 0-7) and `started` (lane 8); the round trip hides under the epilogue, steal() consumes it.
     __device__ __forceinline__ uint32_t peek(int lane) const {
@@ -786,8 +796,8 @@ struct ItemPuller {
     // WAVE 0 (all 64 lanes), after that epilogue -- only the end of a launch gets here: take an item from another group
     // that peek() saw work in, else the first item of a workgroup that has not started yet.  Every lane returns the same
     // value; in the common case (nothing left anywhere) no memory operation is issued here.
-    __device__ __forceinline__ int steal(int lane, uint32_t seen) {
-        const unsigned dd = (unsigned)__builtin_amdgcn_readfirstlane((int)dead);
+    __device__ __forceinline__ int steal(int lane, uint32_t seen, int* slot) const {
+        const unsigned dd = (unsigned)__builtin_amdgcn_readfirstlane(slot[3]);
         const bool cand = lane < 8 && !((dd >> lane) & 1u) && (gcount(lane) - nstatic(lane)) > (int)seen;
         unsigned m = (unsigned)__ballot(cand) & 0xFFu;
         m = ((m >> grp) | (m << (8 - grp))) & 0xFFu;          // bit g: group (grp + g) & 7
@@ -800,7 +810,7 @@ struct ItemPuller {
             if (lane == 0) c = __hip_atomic_fetch_add(ctr + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
             if (c < (uint32_t)left) return (nstatic(x) + (int)c) * 8 + x;
-            if (lane == 0) dead |= 1u << x;
+            if (lane == 0) slot[3] |= 1 << x;
         }
         const int g = (int)gridDim.x;
         const int nstart = __builtin_amdgcn_readlane((int)seen, 8);
@@ -913,8 +923,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
     if (item >= nitems) return;
     ItemPuller pl;
     pl.init(ep, nitems, tid);
-    int* slot = reinterpret_cast<int*>(smem + 4 * H_IMG);      // the next item, published by thread 0
-    pl.claim(tid);                                             // the item after this one: in flight under the whole first item
+    int* slot = reinterpret_cast<int*>(smem + 4 * H_IMG);      // scheduler words of thread 0 (see ItemPuller)
+    uint32_t fo, pend;
+    pl.start(tid, fo, pend);                                   // in flight under the first loads
     int m0, n0, kt0, kt1;
     item_coords(item, m0, n0, kt0, kt1);
     __amdgpu_buffer_rsrc_t ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
@@ -923,8 +934,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
         glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
     }
-    if (pl.ctr && tid == 0) slot[1] = (int)pl.first_old;
-    bool first = pl.ctr != nullptr;
+    bool run = true;      // false: this workgroup's first item was taken by another one before it got to run
+    if (pl.ctr) {
+        if (tid == 0) { slot[1] = (int)fo; slot[2] = (int)pend; slot[3] = 0; }
+        __syncthreads();
+        run = __builtin_amdgcn_readfirstlane(slot[1]) == 0;
+    }
     while (true) {
         f32x4 acc[8][4];
 #pragma unroll
@@ -932,17 +947,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();      // stage 0 of this item has landed (vmcnt(0) rides on the barrier); previous epilogue left stage 1
-        bool skip = false;    // this workgroup's first item was taken by another one before it got to run
-        if (first) {
-            first = false;
-            skip = __builtin_amdgcn_readfirstlane(slot[1]) != 0;
-            if (skip) {
-                if (tid == 0) *slot = pl.claimed();
-                __syncthreads();
-            }
-        }
         bf16x8 diag_a[2][2][4], diag_b[2][4];       // GEMM_DIAG 2 / 4 only
-        for (int kt = kt0; kt < kt1 && !skip; kt++) {
+        if (!run) kt1 = kt0;                        // (nothing of the scheduler inside the k-loop, see ItemPuller)
+        for (int kt = kt0; kt < kt1; kt++) {
             const int st = (kt - kt0) & 1;
             const char* ia = smem + st * 2 * H_IMG;
             const char* ib = ia + H_IMG;
@@ -960,6 +967,49 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                 glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, k2 * G_BK, wave, lane);
 #endif
             }
+#if GEMM_DIAG == 0
+            {
+                // The k-step as an explicit software pipeline, its order pinned: the fragments of MFMA group g+1 are requested in
+                // front of group g's sixteen MFMAs.  hipcc finds this order by itself in some surroundings and not in others (the
+                // same loop came out with every fragment read waited for at once when the item scheduler's code was added behind
+                // it: forward / dgrad GEMMs -10...-30 %), so it is written down.
+                constexpr int RA = A_KM ? 4 : 8, RB = B_KM ? 4 : 8;        // LDS reads per fragment group (transposed reads come in pairs)
+                bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
+                auto mfma16 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], const int ih) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (SWAP) acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih * 4 + i][j], 0, 0, 0);
+                            else acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[ih * 4 + i][j], 0, 0, 0);
+                        }
+                };
+#pragma unroll
+                for (int j = 0; j < 4; j++) fb0[j] = h_frag<B_KM>(ib, wn * 4 + j, 0, lane);
+#pragma unroll
+                for (int i = 0; i < 4; i++) fa0[i] = h_frag<A_KM>(ia, wm * 8 + i, 0, lane);
+#pragma unroll
+                for (int i = 0; i < 4; i++) fa1[i] = h_frag<A_KM>(ia, wm * 8 + 4 + i, 0, lane);
+                mfma16(fa0, fb0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) fb1[j] = h_frag<B_KM>(ib, wn * 4 + j, 1, lane);
+#pragma unroll
+                for (int i = 0; i < 4; i++) fa0[i] = h_frag<A_KM>(ia, wm * 8 + i, 1, lane);
+                mfma16(fa1, fb0, 1);
+#pragma unroll
+                for (int i = 0; i < 4; i++) fa1[i] = h_frag<A_KM>(ia, wm * 8 + 4 + i, 1, lane);
+                mfma16(fa0, fb1, 0);
+                mfma16(fa1, fb1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, RB + RA, 0);       // head: B(0), A(0,0)
+                __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);            // A(0,1) under group (0,0)
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RB + RA, 0);       // B(1), A(1,0) under group (0,1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);            // A(1,1) under group (1,0)
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 bf16x8 fb[4];
@@ -992,15 +1042,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                         }
                 }
             }
-            if (pl.ctr && kt == kt1 - 1 && tid == 0) *slot = pl.claimed();      // published by the barrier below
+#endif
+            __syncthreads();
+        }
+        if (pl.ctr) {                               // the item claimed a whole item ago, through the slot (one more barrier per item)
+            if (tid == 0) *slot = pl.claimed(slot);
             __syncthreads();
         }
         // next item's first k-slab goes to stage 0 while this item's epilogue runs out of stage 1
         const int cm0 = m0, cn0 = n0;
         int next = pl.ctr ? __builtin_amdgcn_readfirstlane(*slot) : (int)(item + gridDim.x < nitems ? item + gridDim.x : -1);
         bool has_next = next >= 0;
+        uint32_t pend2 = 0;
         if (has_next) {
-            pl.claim(tid);
+            pend2 = pl.claim(tid);
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
@@ -1011,7 +1066,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         }
         uint32_t seen = 0;
         if (!has_next && pl.ctr && wave == 0) seen = pl.peek(lane);
-        if (skip) {
+        if (!run) {
         } else if (SWAP) {
             float* stg = reinterpret_cast<float*>(smem + 2 * H_IMG) + wave * (16 * 68);   // stage 1: [16][68] floats per wave
             const int col = cn0 + wn * 64 + (lane & 7) * 8;
@@ -1064,14 +1119,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             if (!pl.ctr) break;
             __syncthreads();                                   // every wave has read the slot and left the staging area
             if (wave == 0) {
-                const int got = pl.steal(lane, seen);
+                const int got = pl.steal(lane, seen, slot);
                 if (lane == 0) *slot = got;
             }
             __syncthreads();
             next = __builtin_amdgcn_readfirstlane(*slot);
             if (next < 0) break;
             pl.follow(next);
-            pl.claim(tid);
+            pend2 = pl.claim(tid);
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
@@ -1080,6 +1135,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                 glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
             }
         }
+        run = true;
+        if (pl.ctr && tid == 0) slot[2] = (int)pend2;       // parked before the next item's first barrier
         item = next;
     }
 }
@@ -1218,8 +1275,9 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
     if (item >= nitems) return;
     ItemPuller pl;
     pl.init(ep, nitems, tid);
-    int* slot = reinterpret_cast<int*>(smem + NST * STAGE);   // the next item, published by thread 0
-    pl.claim(tid);             // OLDER than every DMA below: the counted vmcnt waits stay conservative
+    int* slot = reinterpret_cast<int*>(smem + NST * STAGE);   // scheduler words of thread 0 (see ItemPuller)
+    uint32_t fo, pend;
+    pl.start(tid, fo, pend);   // OLDER than every DMA below: the counted vmcnt waits stay conservative
     int nstamp = 0;
     auto stamp = [&](int id) {
         if (DIAG && stamps && blockIdx.x == 17 && tid == 0 && nstamp < 250) {
@@ -1273,26 +1331,21 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
     for (int i = 0; i < AHEAD; i++)
         if (kt0 + i < kt1) issue(kt0 + i, i);
 
-    if (pl.ctr && tid == 0) slot[1] = (int)pl.first_old;
-    bool first = pl.ctr != nullptr;
+    bool run = true;      // false: this workgroup's first item was taken by another one before it got to run
+    if (pl.ctr) {
+        if (tid == 0) { slot[1] = (int)fo; slot[2] = (int)pend; slot[3] = 0; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        run = __builtin_amdgcn_readfirstlane(slot[1]) == 0;
+        if (!run) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the speculative stages have landed: their buffers may be refilled
+    }
     while (true) {
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int n = kt1 - kt0;
-        bool skip = false;    // this workgroup's first item was taken by another one before it got to run
-        if (first) {
-            first = false;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            skip = __builtin_amdgcn_readfirstlane(slot[1]) != 0;
-            if (skip) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the speculative stages have landed: their buffers may be refilled
-                n = 0;
-            }
-        }
+        const int n = run ? kt1 - kt0 : 0;
         // Software pipeline ACROSS the barrier: the wait+barrier that publishes stage t+1 sits inside stage t's 32
         // MFMAs and stage t+1's B fragments + first A fragment are read right after it, under the remaining MFMAs.
         bf16x8 fb[4], fa0;
@@ -1378,7 +1431,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             for (int t = 0; t < n; t++) run_stage(t, std::integral_constant<int, -1>());
         }
         stamp(20);
-        if (pl.ctr && tid == 0) *slot = pl.claimed();
+        if (pl.ctr && tid == 0) *slot = pl.claimed(slot);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave has finished reading the stages of this item
         stamp(21);
@@ -1388,8 +1441,9 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         void* Cit = slab_stride ? (void*)((float*)C + (int64_t)cur_split * slab_stride) : C;
         int next = pl.ctr ? __builtin_amdgcn_readfirstlane(*slot) : (int)(item + gridDim.x < nitems ? item + gridDim.x : -1);
         bool has_next = next >= 0;
+        uint32_t pend2 = 0;
         if (has_next) {
-            pl.claim(tid);                     // before the stage DMAs (older in the vmcnt queue)
+            pend2 = pl.claim(tid);             // before the stage DMAs (older in the vmcnt queue)
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
@@ -1400,7 +1454,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         stamp(22);
         uint32_t seen = 0;
         if (!has_next && pl.ctr && wave == 0) seen = pl.peek(lane);
-        if (skip) {
+        if (!run) {
         } else if (SWAP) {
             // per wave [16 rows][64 floats] = 4 KiB, 16-byte chunks xor-swizzled by the row
             float* stg = reinterpret_cast<float*>(smem + (NST - 1) * STAGE + A_IMG) + wave * (16 * 64);
@@ -1461,7 +1515,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (wave == 0) {
-                const int got = pl.steal(lane, seen);
+                const int got = pl.steal(lane, seen, slot);
                 if (lane == 0) *slot = got;
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1469,7 +1523,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             next = __builtin_amdgcn_readfirstlane(*slot);
             if (next < 0) break;
             pl.follow(next);
-            pl.claim(tid);
+            pend2 = pl.claim(tid);
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
@@ -1477,6 +1531,8 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             for (int i = 0; i < AHEAD; i++)
                 if (kt0 + i < kt1) issue(kt0 + i, i);
         }
+        run = true;
+        if (pl.ctr && tid == 0) slot[2] = (int)pend2;       // parked before the next item's k-loop
         item = next;
         // the epilogue's stores/atomics sit in the same vmcnt queue behind the prefetched stages: drain them so the
         // counted waits of the next item see only its own DMA (the other workgroup on the CU keeps the pipes busy)
@@ -1584,7 +1640,7 @@ template <bool A_KM, bool B_KM>
 static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
                        void* C, int ldc, const Epilogue& ep, int per, int nsplit, int tiles_n, int ntiles) {
     static bool attr_set = false;
-    const size_t smem = 4 * H_IMG + 16;                                             // + the item slot
+    const size_t smem = 4 * H_IMG + 32;                                             // + the scheduler words
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1621,16 +1677,19 @@ static void launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M,
 // host launcher
 // =================================================================================================
 // Item-counter workspace of the persistent kernels (ItemPuller): per stream, two sets of eight counters, one 128-byte line
-// each; `started` and one first-item flag per workgroup; consecutive launches on a stream alternate sets and every launch zeroes the other one.  COMPOSER_GEMM_STATIC=1
-// keeps the round-2 static striding (A/B timing).
+// each; `started` and one first-item flag per workgroup; consecutive launches on a stream alternate sets and every launch zeroes the other one.
 #include <mutex>
 #include <map>
 #define CHECK_SCHED(expr) do { int rc_ = (expr); if (rc_ != CMP_OK) return rc_; } while (0)
 struct SchedWs { uint32_t* dev = nullptr; int parity = 0; };
-static int sched_next(hipStream_t s, Epilogue& ep) {
-    static const bool is_static = [] { const char* e = getenv("COMPOSER_GEMM_STATIC"); return e && e[0] == '1'; }();
+static int sched_next(hipStream_t s, Epilogue& ep, bool dp) {
+    // default: counters when the launch belongs to a data-parallel job (a communicator exists: RCCL kernels may hold CUs), static
+    // striding otherwise (undisturbed, the counters cost 0-1.3 % -- an extra barrier and LDS word per item);
+    // COMPOSER_GEMM_ITEMS=dynamic / static (read per call) overrides
+    const char* e = getenv("COMPOSER_GEMM_ITEMS");
+    const bool dyn = e ? e[0] == 'd' : dp;
     ep.sched = ep.sched_clear = nullptr;
-    if (is_static) return CMP_OK;
+    if (!dyn) return CMP_OK;
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, SchedWs> tab;
     int dev = 0;
@@ -1744,7 +1803,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             // split-K: partial slabs + reduce when the registered workspace is large enough, else f32 atomics
             const bool slabs = ep.atomic && nsplit > 1 && ldc == N && (N % 4 == 0) && g_slab_ws &&
                                (size_t)nsplit * M * N * 4 <= g_slab_bytes && !(flags & 128);
-            CHECK_SCHED(sched_next(s, ep));
+            CHECK_SCHED(sched_next(s, ep, ex.dp));
             Epilogue ep2 = ep;
             if (slabs) ep2.atomic = 0;
             const bool swap = !ep2.atomic;
@@ -1765,7 +1824,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             const int g1 = std::min(ntiles * nsplit, max_wgs);
             const bool swap = !ep.atomic;
             ep.colsum = colsum_out;
-            CHECK_SCHED(sched_next(s, ep));
+            CHECK_SCHED(sched_next(s, ep, ex.dp));
             if (!ta && !tb) colsum_fused = launch_256<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
             else if (!ta && tb) colsum_fused = launch_256<true, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
             else if (ta && !tb) colsum_fused = launch_256<false, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);

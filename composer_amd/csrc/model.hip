@@ -533,6 +533,7 @@ static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A
     if (splitk > 1 && det) { ex.slab_ws = (float*)m->slab; ex.slab_bytes = (size_t)m->slab_bytes; }
     ex.role = m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1);         // forward announces 0; backward: A^T = wgrad, else dgrad
     ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;              // leave CUs to the concurrent all-reduce kernels
+    ex.dp = m->ctx->comm != nullptr;                                   // RCCL kernels may hold CUs: dynamic item scheduling
     CHECK_RC(gemm_run(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
                       out_fp32, splitk, p_drop, m->drop_seed(), rng_stream, flags, ex));
     if (det && colsum) CHECK_RC(colsum_det(m, C, ldc, colsum, M, N));

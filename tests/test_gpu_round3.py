@@ -236,8 +236,10 @@ def test_item_stealing_beside_a_cu_hog_keeps_the_results():
     V, E, H, L, W, T, B = 390, 256, 4, 2, 256, 256, 32
     params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=2).items()}
     x, y = O.synthetic_batch(np.random.default_rng(9), V, B, T)
+    import os
     curves = []
     for hog in (False, True, True):
+        os.environ["COMPOSER_GEMM_ITEMS"] = "dynamic" if hog else "static"      # (without a communicator the default is static striding)
         m = Transformer(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, dtype="bf16", seed=4, max_batch=B, max_seq=W)
         m.set_weights(params)
         losses = []
@@ -248,5 +250,24 @@ def test_item_stealing_beside_a_cu_hog_keeps_the_results():
         m.synchronize()
         curves.append(losses)
         m.close()
+    os.environ.pop("COMPOSER_GEMM_ITEMS", None)
     for c in curves[1:]:
         assert np.allclose(c, curves[0], rtol=2e-4, atol=0), (c, curves[0])
+
+
+@pytest.mark.parametrize("flags", [8, 16, 48])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(384, 640, 256), (1000, 264, 512), (2104, 520, 192), (4096, 1536, 512)])
+def test_persistent_gemms_with_item_counters(ta, tb, M, N, K, flags):
+    """The persistent GEMM kernels (256x256 two-stage, deep pipeline at both tile shapes) with dynamic item scheduling forced
+    (COMPOSER_GEMM_ITEMS=dynamic: per-XCD counters, stealing, first-item flags) on ragged and multi-round item counts."""
+    import os
+    import test_gpu_kernels as K_
+    from composer_amd import _lib
+    lib = _lib.load(); _lib.require_gpu()
+    os.environ["COMPOSER_GEMM_ITEMS"] = "dynamic"
+    try:
+        for _ in range(3):          # consecutive launches alternate the two counter sets
+            K_.test_gemm_layouts(lib, K_.BF16, ta, tb, M, N, K, flags)
+    finally:
+        os.environ.pop("COMPOSER_GEMM_ITEMS", None)
