@@ -1,1 +1,1 @@
-extern "C" const char* cmp_build_key(void) { return "f821bbb4f913d4535cce7c12464e4ad4c2cc1bb9249f4771ca424554dddc2700"; }
+extern "C" const char* cmp_build_key(void) { return "9510d71cf8f297db403eef61bfc4f87d403858221a340bd78524e7170d66c7ae"; }
