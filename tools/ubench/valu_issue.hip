@@ -19,16 +19,16 @@ __global__ void k(float* out, unsigned long long* cyc, int n, int mfma_waves) {
     bf16x8 fa, fb;
     for (int i = 0; i < 8; i++) { fa[i] = (__bf16)(0.01f * (float)(threadIdx.x & 7)); fb[i] = (__bf16)0.5f; }
     const int wave = threadIdx.x >> 6;
-    const bool do_mfma = (MODE == 3) || (MODE == 4 && wave < mfma_waves) || MODE == 5;
-    const bool do_valu = (MODE == 0 || MODE == 1 || MODE == 2) || (MODE == 4 && wave >= mfma_waves) || MODE == 5;
+    const bool do_mfma = (MODE == 3) || (MODE == 4 && wave < mfma_waves);
+    const bool do_valu = (MODE == 0 || MODE == 1 || MODE == 2) || (MODE == 4 && wave >= mfma_waves);
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < n; it++) {
-        if (do_mfma && MODE != 5) {
+        if (do_mfma) {
 #pragma unroll
             for (int j = 0; j < 8; j++) { acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc2, 0, 0, 0); }
         }
-        if (do_valu && MODE != 5) {
+        if (do_valu) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -44,6 +44,22 @@ __global__ void k(float* out, unsigned long long* cyc, int n, int mfma_waves) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 6; i++) a[(j + i) & 15] = fmaf(a[(j + i) & 15], 1.0001f, 0.5f);
+            }
+        }
+        if (MODE == 6 || MODE == 7 || MODE == 8) {   // the same work with the order PINNED: 1 MFMA, then its fillers (sched_group_barrier)
+            constexpr int NF = MODE == 6 ? 5 : (MODE == 7 ? 3 : 8);      // plain fillers per gap; MODE 7 adds one v_exp_f32 per gap
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NF; i++) a[(j + i) & 15] = fmaf(a[(j + i) & 15], 1.0001f, 0.5f);
+                if (MODE == 7) a[(j + 9) & 15] = __builtin_amdgcn_exp2f(a[(j + 9) & 15]);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NF, 0);
+                if (MODE == 7) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
             }
         }
     }
@@ -65,8 +81,9 @@ int main() {
     float* out; unsigned long long* cyc;
     CK(hipMalloc(&out, 256 * 1024 * 4)); CK(hipMalloc(&cyc, 256 * 8));
     const int n = 2000;
-    const char* names[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "mfma 32x32x16 (2 chains)", "MFMA waves + fma waves", "1 MFMA + 6 fma per gap, every wave"};
-    for (int mode = 0; mode < 6; mode++)
+    const char* names[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "mfma 32x32x16 (2 chains)", "MFMA waves + fma waves", "1 MFMA + 6 fma per gap, every wave",
+                           "pinned: 1 MFMA + 5 fma per gap", "pinned: 1 MFMA + 3 fma + 1 exp per gap", "pinned: 1 MFMA + 8 fma per gap"};
+    for (int mode = 0; mode < 9; mode++)
         for (int waves = 4; waves <= 16; waves *= 2) {
             if (mode == 4 && waves < 8) continue;
             std::vector<unsigned long long> h(256);
@@ -77,7 +94,10 @@ int main() {
                     case 2: k<2><<<256, waves * 64>>>(out, cyc, n, 0); break;
                     case 3: k<3><<<256, waves * 64>>>(out, cyc, n, 0); break;
                     case 4: k<4><<<256, waves * 64>>>(out, cyc, n, waves / 2); break;
-                    default: k<5><<<256, waves * 64>>>(out, cyc, n, 0); break;
+                    case 5: k<5><<<256, waves * 64>>>(out, cyc, n, 0); break;
+                    case 6: k<6><<<256, waves * 64>>>(out, cyc, n, 0); break;
+                    case 7: k<7><<<256, waves * 64>>>(out, cyc, n, 0); break;
+                    default: k<8><<<256, waves * 64>>>(out, cyc, n, 0); break;
                 }
                 CK(hipDeviceSynchronize());
             }
@@ -87,7 +107,7 @@ int main() {
             if (mode <= 2) printf("%-36s %d wave(s)/SIMD: %6.2f cycles per wave-instruction per SIMD\n", names[mode], wps, avg / (n * 64.0 * wps));
             else if (mode == 3) printf("%-36s %d wave(s)/SIMD: %6.2f cycles per MFMA per SIMD\n", names[mode], wps, avg / (n * 16.0 * wps));
             else if (mode == 4) printf("%-36s %d wave(s)/SIMD (half MFMA, half fma): %8.0f cycles per iteration (16 MFMA | 64 fma per wave)\n", names[mode], wps, avg / n);
-            else printf("%-36s %d wave(s)/SIMD: %6.2f cycles per (MFMA + 6 fma) per SIMD\n", names[mode], wps, avg / (n * 16.0 * wps));
+            else printf("%-40s %d wave(s)/SIMD: %6.2f cycles per (MFMA + fillers) per SIMD\n", names[mode], wps, avg / (n * 16.0 * wps));
         }
     return 0;
 }
