@@ -1,1 +1,1 @@
-extern "C" const char* cmp_build_key(void) { return "9510d71cf8f297db403eef61bfc4f87d403858221a340bd78524e7170d66c7ae"; }
+extern "C" const char* cmp_build_key(void) { return "e9da94bdfe725cbd24458014d589ec28f85aec97f746ed541a6b7408135f6e2f"; }

@@ -86,6 +86,8 @@ struct cmp_model {
     bf16_t* ST = nullptr;
     void* wdesc = nullptr;     // device table of (offset, rows, cols) for the 4L matrices
     int64_t iterations = 0;
+    int64_t param_version = 0;         // bumped whenever a parameter value changes (cmp_param_set, Adam): the decode state's
+                                       // transposed weight copies are refreshed when it has moved
     // workspace
     int capB = 0, capT = 0;
     std::vector<void*> allocs;

@@ -375,6 +375,7 @@ extern "C" int cmp_param_set(cmp_model* m, const char* name, int kind, const flo
     CMP_REQUIRE(b, "param_set: bad kind %d", kind);
     HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     HIP_CHECK(hipMemcpy(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice));
+    if (kind == 0) m->param_version += 1;
     if (kind == 0 && m->S) {
         int64_t n8 = (p.numel + 7) / 8 * 8;
         CHECK_RC(launch_cast_bf16(m->ctx->stream, m->P + p.offset, m->S + p.offset, n8));
@@ -764,6 +765,7 @@ static int adam(cmp_model* m, float lr) {
         KERNEL_CHECK();
     }
     m->iterations += 1;
+    m->param_version += 1;
     return cmp_k_adam(c->stream, m->P, m->G, m->Am, m->Av, m->S, m->total, lr, 0.9f, 0.999f, 1e-7f, m->iterations, gscale);
 }
 

@@ -271,3 +271,35 @@ def test_persistent_gemms_with_item_counters(ta, tb, M, N, K, flags):
             K_.test_gemm_layouts(lib, K_.BF16, ta, tb, M, N, K, flags)
     finally:
         os.environ.pop("COMPOSER_GEMM_ITEMS", None)
+
+
+def test_decode_state_is_reused_and_follows_the_weights():
+    """cmp_decode_begin keeps its buffers, transposed weights and captured chain from call to call; new weights (set_weights or a
+    train step), another mode, temperature or seed must still take effect -- every call is compared with a FRESH model's."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W = 390, 64, 4, 2, 64
+    pa = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=1, stddev=0.3).items()}
+    pb = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=2, stddev=0.3).items()}
+    prompt = [5, 17, 200]
+
+    def fresh(params, **kw):
+        f = Transformer(V, E, W, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="fp32", max_batch=2, max_seq=W)
+        f.set_weights(params)
+        out = f.generate(prompt, 20, **kw).tolist()
+        f.close()
+        return out
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="fp32", max_batch=2, max_seq=W)
+    m.set_weights(pa)
+    calls = [dict(temperature=0.0, mode="kv"), dict(temperature=1.0, mode="kv", seed=3), dict(temperature=1.0, mode="kv", seed=4),
+             dict(temperature=0.7, mode="literal", seed=3), dict(temperature=0.0, mode="literal"), dict(temperature=0.0, mode="kv")]
+    for kw in calls:
+        assert m.generate(prompt, 20, **kw).tolist() == fresh(pa, **kw), kw
+    m.set_weights(pb)                                               # new parameters: the transposed copies must be rebuilt
+    for kw in calls[:3]:
+        assert m.generate(prompt, 20, **kw).tolist() == fresh(pb, **kw), kw
+    x, y = O.synthetic_batch(np.random.default_rng(0), V, 2, 32)
+    m.train_step(x, y, 1e-2)                                        # ... and after an optimizer step
+    want = O.OracleTransformer(O.Config(V, E, W, L, H), pb)
+    want.train_step(x, y, 1e-2, training=False)
+    assert m.generate(prompt, 12, temperature=0.0, mode="kv").tolist() == want.generate_kv(prompt, 12)
+    m.close()
