@@ -406,7 +406,11 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
     xcd_block(bx, by, H);
+#if ATTN_DIAG == 9                                   // measurement build: every batch row aliases row 0 or 1 (data set stays in L2 / MALL)
+    const int b = (by / H) & 1, hd = by % H;
+#else
     const int b = by / H, hd = by % H;
+#endif
     const int E = H * D;
     const int64_t rs = 3 * E;                        // row stride of qkv
     const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
@@ -871,6 +875,255 @@ __global__ __launch_bounds__(256, A2_MINW) void attn_fwd64_kernel(const bf16_t* 
 }
 
 // =================================================================================================
+// forward, bf16 / D = 64, third structure ("fwd32p"): software-pipelined across 32-key units inside ONE wave.
+// The unit of work is a 32-key sub-tile u with three stages -- S_u = K_u Q^T (4 MFMAs), softmax(S_u) -> P_u (vector),
+// O += V_u^T P_u (4 MFMAs) -- and the instruction stream of step u is { MFMAs of S_{u+1} and of PV_{u-1} } interleaved with
+// { softmax of unit u }: the vector work always has eight independent MFMAs to sit between, and the LDS operands of step u+1
+// are read at the end of step u.  A wave owns 32 query rows; K/V tiles come through the LDS-DMA ring of the kernel above with
+// FIVE stages (tiles t-1, t, t+1 are read in iteration t; t+2 and t+3 are in flight), one barrier per 64-key tile.
+// The online-softmax rescale of O for unit u is applied AFTER PV_{u-1} has been accumulated (P_{u-1} was scaled with the old
+// running maximum).  Selected by COMPOSER_ATTN64=pipe; measurements in DESIGN.md "Attention, round 3".
+// =================================================================================================
+#define A3_STAGES 5
+#ifndef A3_PIN
+#define A3_PIN 1
+#endif
+// A3_DIAG (measurement builds only -- results are wrong), a bit mask: 1 no exponentials, 2 no softmax arithmetic, 4 no
+// running-maximum head, 8 no barrier / waits / DMA inside the loop, 16 no MFMAs, 32 no V reads from LDS, 64 no K reads from LDS,
+// 128 every batch row aliases batch row 0 or 1 (the whole data set stays in L2 / MALL)
+#ifndef A3_DIAG
+#define A3_DIAG 0
+#endif
+#define A3D(bit) ((A3_DIAG & (bit)) != 0)
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                             float* __restrict__ lse, int Tn, int H, float scale, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    xcd_block(bx, by, H);
+#if A3D(128)
+    const int b = (by / H) & 1, hd = by % H;
+#else
+    const int b = by / H, hd = by % H;
+#endif
+    const int E = H * 64;
+    const int64_t rs = 3 * E;
+    const bf16_t* qg = qkv + (int64_t)b * Tn * rs + hd * 64;
+    bf16_t* og = o + (int64_t)b * Tn * E + hd * 64;
+    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const int nb = cdiv(Tn, 128);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(a2_lds_char*)smem_raw;
+    const int64_t span = ((int64_t)(Tn - 1) * rs + 64) * 2;
+    const a2_v4i srk = a2_make_srd(qg + E, span), srv = a2_make_srd(qg + 2 * E, span);
+    const int rsb = (int)(rs * 2);
+    int kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), pc = lane & 7;
+        kvo[i] = row * rsb + ((pc ^ ((row >> 1) & 7)) << 4);
+        vvo[i] = row * rsb + ((pc ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    auto issue = [&](int t) {
+        const int soff = t * 64 * rsb;
+        const uint32_t kb = lds0 + (t % A3_STAGES) * A2_STAGE + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srk, kb + i * 1024, kvo[i], soff);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srv, kb + A2_IMG + i * 1024, vvo[i], soff);
+    };
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) koff[s] = (lane & 31) * 128 + (((2 * s + h) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int G = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    int voffr[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) voffr[dt] = (4 * (G >> 1) + qq) * 128 + ((dt ^ ((qq >> 1) & 1)) << 6) + 32 * (G & 1) + 8 * pp;
+
+    for (int ph = 0; ph < 2; ph++) {
+        const int hi = nb - 1 - bx;
+        const int qb = ph == 0 ? hi : (bx < hi ? bx : -1);
+        if (qb < 0) break;
+        const int q = qb * 128 + 32 * wave + (lane & 31);
+        const bool qvalid = q < Tn;
+        bf16x8 qf[4];
+        load_bfrags<bf16_t, 64>(qf, qg, rs, q, qvalid, h);
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
+        f32x16 oacc[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+        const int kv_end = min(Tn, qb * 128 + 128);
+        const int nt = cdiv(kv_end, 64), nint = qb * 2;                  // tiles; the first nint lie below every query row of the block
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (i < nt) issue(i);
+
+        f32x16 scA, scB;
+        bf16x8 pbA[2], pbB[2];
+        bf16x8 kf[4], va[2][2];                                             // operands of the NEXT step's MFMAs, read one step ahead
+        auto load_k = [&](const char* Kn) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) kf[s] = *reinterpret_cast<const bf16x8*>(Kn + koff[s]);
+        };
+        auto load_v = [&](const char* Vp) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const char* a = Vp + (16 * s) * 128 + voffr[dt];
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
+                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 8 * 128));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { va[s][dt][j] = lo[j]; va[s][dt][4 + j] = hi4[j]; }
+                }
+        };
+        // one pipeline step: softmax of `cur` (unit with first key k0) -> pcur, while the matrix pipe computes nxt = K Q^T (kf) and,
+        // when PV, O += V^T pprev (va); then the operands of the following step are read (Kn2: its K rows, Vp2: its V rows)
+        auto unit = [&](auto MASKT, auto PVT, f32x16& cur, f32x16& nxt, bf16x8 (&pcur)[2], const bf16x8 (&pprev)[2], const char* Kn2,
+                        const char* Vp2, const int k0) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(MASKT)::value;
+            constexpr bool PV = decltype(PVT)::value;
+            if (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = k0 + rho(r, h);
+                    if (key > q || key >= Tn) cur[r] = neg_big;
+                }
+            }
+#if A3D(4)
+            const bool need = false;
+            float alpha = 1.0f;
+            if (m < -1e30f) m = 8.0f;
+#else
+            const float mloc = half_max(max16(cur));
+            const float mnew = fmaxf(m, mloc);
+            const bool need = !__all(mnew == m);
+            float alpha = 1.0f;
+            if (need) {
+                alpha = fast_exp2((m - mnew) * c2);
+                lsum *= alpha;
+                m = mnew;
+            }
+#endif
+            const float mc = m * c2;
+            __builtin_amdgcn_sched_barrier(0);
+#if A3D(16)
+#pragma unroll
+            for (int r = 0; r < 16; r++) nxt[r] = (float)kf[r & 3][r & 7] * 1e-3f + (float)(k0 + r);
+            if (PV) {
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++) { asm volatile("" ::"v"(va[s][dt]), "v"(pprev[s])); oacc[dt][(2 * s + dt) & 15] += 1.0f; }
+            }
+#else
+#pragma unroll
+            for (int r = 0; r < 16; r++) nxt[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], nxt, 0, 0, 0);
+            if (PV) {
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pprev[s], oacc[dt], 0, 0, 0);
+            }
+#endif
+#if A3D(2)
+            f32x2 ps = {cur[0], cur[1]};
+#elif A3D(1)
+            f32x2 ps = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r++) { cur[r] = fmaf(cur[r], c2, -mc); ps[r & 1] += cur[r]; }
+#else
+            f32x2 ps = exp2_scaled16(cur, c2, -mc, f32x2{0.f, 0.f});
+#endif
+            lsum += ps[0] + ps[1];
+#if !A3D(2)
+            if constexpr (DROP) mask16_qlane<true>(cur, rowh, k0, h, drop.thr);
+#endif
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) pcur[s][j] = (bf16_t)cur[8 * s + j];
+#if A3_PIN
+            // pinned interleave: one MFMA per slice of the vector work
+#pragma unroll
+            for (int i = 0; i < (PV ? 8 : 4); i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, DROP ? (PV ? 12 : 24) : (PV ? 5 : 10), 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, PV ? 2 : 4, 0);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(pcur[0]), "+v"(pcur[1]), "+v"(lsum));     // keeps the vector work of this unit inside this block
+#if !A3D(64)
+            load_k(Kn2);
+#endif
+#if !A3D(32)
+            load_v(Vp2);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (need) {                                                     // rescale O AFTER P_{u-1} (old maximum) went in
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+            }
+        };
+        auto iter = [&](auto MASKT, auto FIRSTT, const int t) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(FIRSTT)::value;
+            // tiles <= t + 1 have landed (own pieces: counted wait; the others': the barrier); tile t + 2 may still fly.  The LDS reads
+            // in flight here (operands of step A, tiles t-1 and t) do not touch the stage that is re-filled below (tile t-2's).
+#if !A3D(8)
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 3 < nt) issue(t + 3);
+#endif
+            const char* St = smem_raw + (t % A3_STAGES) * A2_STAGE;
+            const char* Sn = smem_raw + ((t + 1) % A3_STAGES) * A2_STAGE;
+            // step A: unit 2t (S_{2t+1} from K(t) rows 32.., PV of unit 2t-1); then read step B's operands: K(t+1) rows 0.., V(t) rows 0..
+            unit(MASKT, std::integral_constant<bool, !FIRST>{}, scA, scB, pbA, pbB, Sn, St + A2_IMG, t * 64);
+            // step B: unit 2t+1; then step A(t+1)'s operands: K(t+1) rows 32.., V(t) rows 32..
+            unit(MASKT, std::true_type{}, scB, scA, pbB, pbA, Sn + 4096, St + A2_IMG + 32 * 128, t * 64 + 32);
+        };
+        // prologue: S_0, and the operands of step A(0): K(0) rows 32.. (no PV in the very first step)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_k(smem_raw);
+#pragma unroll
+        for (int r = 0; r < 16; r++) scA[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) scA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], scA, 0, 0, 0);
+        load_k(smem_raw + 4096);
+        load_v(smem_raw + A2_IMG);                                          // unused by the first step (finite or not: never multiplied)
+        if (nint > 0) iter(std::false_type{}, std::true_type{}, 0);
+        else iter(std::true_type{}, std::true_type{}, 0);
+        int t = 1;
+        for (; t < nint; t++) iter(std::false_type{}, std::false_type{}, t);
+        for (; t < nt; t++) iter(std::true_type{}, std::false_type{}, t);
+        // drain: PV of the last unit (its V rows were read by the last step)
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pbB[s], oacc[dt], 0, 0, 0);
+        const float ltot = half_sum(lsum);
+        const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q, qvalid, dt, oacc[dt], inv, h);
+        if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = m * scale + logf(ltot);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// =================================================================================================
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
 // With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
 // =================================================================================================
@@ -1180,14 +1433,32 @@ static int attn_grid_x(int Tn, int BH) {
 static int attn64_mode() {
     const char* e = getenv("COMPOSER_ATTN64");
     if (!e) return 0;
-    return e[0] == 'o' ? -1 : (e[0] == 'f' ? 1 : 0);
+    return e[0] == 'o' ? -1 : (e[0] == 'f' ? 1 : (e[0] == 'p' ? 2 : 0));
 }
 template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
     if constexpr (std::is_same<T, bf16_t>::value && D == 64) {
         const int nb = cdiv(Tn, 256), pairs = (nb + 1) / 2;
         const int mode = attn64_mode();
-        if (mode > 0 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
+        if (mode == 2 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
+            const size_t smem3 = A3_STAGES * A2_STAGE;
+            static bool attr3 = false;
+            if (!attr3) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
+                attr3 = true;
+            }
+            const int nb3 = cdiv(Tn, 128);
+            dim3 grid((nb3 + 1) / 2, B * H);
+            const double flops = 2.0 * B * H * (double)Tn * Tn * D;
+            PROF_START(3, s);
+            if (d.thr) attn_fwd32p_kernel<true><<<grid, 256, smem3, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            else attn_fwd32p_kernel<false><<<grid, 256, smem3, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            PROF_STOP(3, s, flops);
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+        if (mode == 1 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
             const size_t smem2 = A2_STAGES * A2_STAGE;
             static bool attr = false;
             if (!attr) {

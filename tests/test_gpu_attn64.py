@@ -12,10 +12,11 @@ pytestmark = pytest.mark.gpu
 lib = K.lib
 
 
-@pytest.fixture(autouse=True)
-def force_attn64():
+@pytest.fixture(autouse=True, params=["force", "pipe"])
+def force_attn64(request):
+    """force: 64 rows per wave ("fwd64"); pipe: 32 rows per wave, software-pipelined across 32-key units ("fwd32p")"""
     old = os.environ.get("COMPOSER_ATTN64")
-    os.environ["COMPOSER_ATTN64"] = "force"
+    os.environ["COMPOSER_ATTN64"] = request.param
     yield
     if old is None:
         os.environ.pop("COMPOSER_ATTN64", None)
