@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256, A2_MINW) void attn_fwd64_kernel(const bf16_t* 
 #endif
 // A3_DIAG (measurement builds only -- results are wrong), a bit mask: 1 no exponentials, 2 no softmax arithmetic, 4 no
 // running-maximum head, 8 no barrier / waits / DMA inside the loop, 16 no MFMAs, 32 no V reads from LDS, 64 no K reads from LDS,
-// 128 every batch row aliases batch row 0 or 1 (the whole data set stays in L2 / MALL)
+// 128 every batch row aliases batch row 0 or 1 (the whole data set stays in L2 / MALL), 256 no output stores, 512 no prologue DMA
 #ifndef A3_DIAG
 #define A3_DIAG 0
 #endif
@@ -958,9 +958,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const bf16_t* __res
         float m = -INFINITY, lsum = 0.f;
         const int kv_end = min(Tn, qb * 128 + 128);
         const int nt = cdiv(kv_end, 64), nint = qb * 2;                  // tiles; the first nint lie below every query row of the block
+#if !A3D(512)
 #pragma unroll
         for (int i = 0; i < 3; i++)
             if (i < nt) issue(i);
+#endif
 
         f32x16 scA, scB;
         bf16x8 pbA[2], pbB[2];
@@ -1115,9 +1117,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const bf16_t* __res
             for (int dt = 0; dt < 2; dt++) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pbB[s], oacc[dt], 0, 0, 0);
         const float ltot = half_sum(lsum);
         const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#if A3D(256)
+        if (inv == 123.456f)
+#endif
+        {
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q, qvalid, dt, oacc[dt], inv, h);
-        if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = m * scale + logf(ltot);
+            for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q, qvalid, dt, oacc[dt], inv, h);
+            if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = m * scale + logf(ltot);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
