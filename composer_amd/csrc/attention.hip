@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256, A2_MINW) void attn_fwd64_kernel(const bf16_t* 
 #endif
 // A3_DIAG (measurement builds only -- results are wrong), a bit mask: 1 no exponentials, 2 no softmax arithmetic, 4 no
 // running-maximum head, 8 no barrier / waits / DMA inside the loop, 16 no MFMAs, 32 no V reads from LDS, 64 no K reads from LDS,
-// 128 every batch row aliases batch row 0 or 1 (the whole data set stays in L2 / MALL), 256 no output stores, 512 no prologue DMA
+// 128 every batch row aliases batch row 0 or 1 (the whole data set stays in L2 / MALL), 256 no output stores, 512 no prologue DMA, 1024 one tile per block
 #ifndef A3_DIAG
 #define A3_DIAG 0
 #endif
@@ -957,7 +957,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const bf16_t* __res
             for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
         float m = -INFINITY, lsum = 0.f;
         const int kv_end = min(Tn, qb * 128 + 128);
+#if A3D(1024)
+        const int nt = 1, nint = 0;
+#else
         const int nt = cdiv(kv_end, 64), nint = qb * 2;                  // tiles; the first nint lie below every query row of the block
+#endif
 #if !A3D(512)
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -1125,6 +1129,173 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const bf16_t* __res
             for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q, qvalid, dt, oacc[dt], inv, h);
             if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = m * scale + logf(ltot);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// =================================================================================================
+// forward, bf16 / D = 64, fourth structure ("fwd32d"): the occupancy experiment.  The round-2 tile body (a 32-key unit at a time:
+// 4 score MFMAs, softmax, 4 PV MFMAs; 32 query rows per wave) fed by the LDS-DMA ring instead of register-staged loads, so that
+// the per-lane state fits 128 registers and FOUR workgroups share a CU (4 waves per SIMD; two ring stages = 32 KiB each).
+// Selected by COMPOSER_ATTN64=dense.
+// =================================================================================================
+#ifndef A4_MINW
+#define A4_MINW 4
+#endif
+#ifndef A4_STAGES
+#define A4_STAGES 2
+#endif
+template <bool DROP>
+__global__ __launch_bounds__(256, A4_MINW) void attn_fwd32d_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                                  float* __restrict__ lse, int Tn, int H, float scale, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    xcd_block(bx, by, H);
+    const int b = by / H, hd = by % H;
+    const int E = H * 64;
+    const int64_t rs = 3 * E;
+    const bf16_t* qg = qkv + (int64_t)b * Tn * rs + hd * 64;
+    bf16_t* og = o + (int64_t)b * Tn * E + hd * 64;
+    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const int nb = cdiv(Tn, 128);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(a2_lds_char*)smem_raw;
+    const int64_t span = ((int64_t)(Tn - 1) * rs + 64) * 2;
+    const a2_v4i srk = a2_make_srd(qg + E, span), srv = a2_make_srd(qg + 2 * E, span);
+    const int rsb = (int)(rs * 2);
+    int kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), pc = lane & 7;
+        kvo[i] = row * rsb + ((pc ^ ((row >> 1) & 7)) << 4);
+        vvo[i] = row * rsb + ((pc ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    auto issue = [&](int t) {
+        const int soff = t * 64 * rsb;
+        const uint32_t kb = lds0 + (t % A4_STAGES) * A2_STAGE + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srk, kb + i * 1024, kvo[i], soff);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srv, kb + A2_IMG + i * 1024, vvo[i], soff);
+    };
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) koff[s] = (lane & 31) * 128 + (((2 * s + h) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int G = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    int voffr[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) voffr[dt] = (4 * (G >> 1) + qq) * 128 + ((dt ^ ((qq >> 1) & 1)) << 6) + 32 * (G & 1) + 8 * pp;
+
+    for (int ph = 0; ph < 2; ph++) {
+        const int hi = nb - 1 - bx;
+        const int qb = ph == 0 ? hi : (bx < hi ? bx : -1);
+        if (qb < 0) break;
+        const int q0w = qb * 128 + 32 * wave;
+        const int q = q0w + (lane & 31);
+        const bool qvalid = q < Tn;
+        bf16x8 qf[4];
+        load_bfrags<bf16_t, 64>(qf, qg, rs, q, qvalid, h);
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
+        f32x16 oacc[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+        const int kv_end = min(Tn, qb * 128 + 128);
+        const int nt = cdiv(kv_end, 64), nint = qb * 2;
+#pragma unroll
+        for (int i = 0; i < A4_STAGES - 1; i++)
+            if (i < nt) issue(i);
+
+        // one 32-key unit, complete: scores, online softmax, PV.  MASK (compile time): compare keys with queries / Tn
+        auto unit = [&](auto MASKT, const char* Ku, const char* Vu, const int k0) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(MASKT)::value;
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ku + koff[s]);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
+            }
+            if (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = k0 + rho(r, h);
+                    if (key > q || key >= Tn) sc[r] = neg_big;
+                }
+            }
+            const float mloc = half_max(max16(sc));
+            const float mnew = fmaxf(m, mloc);
+            if (!__all(mnew == m)) {
+                const float alpha = fast_exp2((m - mnew) * c2);
+                lsum *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+                m = mnew;
+            }
+            const float mc = m * c2;
+            const f32x2 ps = exp2_scaled16(sc, c2, -mc, f32x2{0.f, 0.f});
+            lsum += ps[0] + ps[1];
+            if constexpr (DROP) mask16_qlane<true>(sc, rowh, k0, h, drop.thr);
+            bf16x8 pb[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) pb[s][j] = (bf16_t)sc[8 * s + j];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const char* a = Vu + (16 * s) * 128 + voffr[dt];
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
+                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 8 * 128));
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi4[j]; }
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, pb[s], oacc[dt], 0, 0, 0);
+                }
+        };
+        auto step = [&](auto MASKT, const int t) __attribute__((always_inline)) {
+            // tile t has landed (own pieces: counted wait; the others': the barrier); every wave has left tile t-1, whose stage is re-filled
+            {
+                const int ahead = min(nt - 1 - t, A4_STAGES - 2);
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + A4_STAGES - 1 < nt) issue(t + A4_STAGES - 1);
+            const char* Ks = smem_raw + (t % A4_STAGES) * A2_STAGE;
+            const char* Vs = Ks + A2_IMG;
+            unit(MASKT, Ks, Vs, t * 64);
+            // the second unit of a diagonal tile lies entirely above the diagonal for the waves whose rows end below it
+            if (!decltype(MASKT)::value || t * 64 + 32 <= q0w + 31) unit(MASKT, Ks + 4096, Vs + 32 * 128, t * 64 + 32);
+        };
+        int t = 0;
+        for (; t < nint; t++) step(std::false_type{}, t);
+        for (; t < nt; t++) {
+            if (t * 64 <= q0w + 31) step(std::true_type{}, t);
+            else {                                                          // nothing to do in this tile: keep the barrier and the ring going
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t + A4_STAGES - 1 < nt) issue(t + A4_STAGES - 1);
+            }
+        }
+        const float ltot = half_sum(lsum);
+        const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q, qvalid, dt, oacc[dt], inv, h);
+        if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = m * scale + logf(ltot);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -1440,13 +1611,31 @@ static int attn_grid_x(int Tn, int BH) {
 static int attn64_mode() {
     const char* e = getenv("COMPOSER_ATTN64");
     if (!e) return 0;
-    return e[0] == 'o' ? -1 : (e[0] == 'f' ? 1 : (e[0] == 'p' ? 2 : 0));
+    return e[0] == 'o' ? -1 : (e[0] == 'f' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'd' ? 3 : 0)));
 }
 template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
     if constexpr (std::is_same<T, bf16_t>::value && D == 64) {
         const int nb = cdiv(Tn, 256), pairs = (nb + 1) / 2;
         const int mode = attn64_mode();
+        if (mode == 3 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
+            const size_t smem4 = A4_STAGES * A2_STAGE;
+            static bool attr4 = false;
+            if (!attr4) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4));
+                attr4 = true;
+            }
+            const int nb4 = cdiv(Tn, 128);
+            dim3 grid((nb4 + 1) / 2, B * H);
+            const double flops = 2.0 * B * H * (double)Tn * Tn * D;
+            PROF_START(3, s);
+            if (d.thr) attn_fwd32d_kernel<true><<<grid, 256, smem4, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            else attn_fwd32d_kernel<false><<<grid, 256, smem4, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            PROF_STOP(3, s, flops);
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
         if (mode == 2 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
             const size_t smem3 = A3_STAGES * A2_STAGE;
             static bool attr3 = false;

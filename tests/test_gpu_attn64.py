@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 lib = K.lib
 
 
-@pytest.fixture(autouse=True, params=["force", "pipe"])
+@pytest.fixture(autouse=True, params=["force", "pipe", "dense"])
 def force_attn64(request):
-    """force: 64 rows per wave ("fwd64"); pipe: 32 rows per wave, software-pipelined across 32-key units ("fwd32p")"""
+    """force: 64 rows per wave ("fwd64"); pipe: 32 rows per wave, software-pipelined across 32-key units ("fwd32p");
+    dense: 32 rows per wave, round-2 tile body on the LDS-DMA ring at four waves per SIMD ("fwd32d")"""
     old = os.environ.get("COMPOSER_ATTN64")
     os.environ["COMPOSER_ATTN64"] = request.param
     yield
