@@ -1018,7 +1018,6 @@ extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int pas
                            float* logits_out) {
     CMP_REQUIRE(m && x && logits_out, "forward: null argument");
     CMP_REQUIRE(past_len >= 0 && (past_len == 0 || past != nullptr), "forward: past_len %d without past tensors", past_len);
-    CMP_REQUIRE(!(training && past_len > 0), "forward: training=True together with `past` is not supported");
     CMP_REQUIRE(T > 0 && T + past_len <= m->W, "forward: positions %d..%d exceed window_size %d (wpe rows, transformer.py:675-679,786)",
                 past_len, past_len + T - 1, m->W);
     HIP_CHECK(hipSetDevice(m->ctx->device));

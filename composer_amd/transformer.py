@@ -240,14 +240,13 @@ class Transformer:
         `past` = an earlier call's presents (L tensors [2,B,H,Tp,D], or the lazy Presents object): only the last input
         token is used (:735-737), it sits at position Tp (:760-770), its keys/values are appended to `past` (:423-426)
         and the returned presents hold Tp+1 positions.  `training=True` (:916-917) applies dropout with the masks a train
-        step at the current optimizer iteration would draw."""
+        step at the current optimizer iteration would draw; together with `past` the attention-probability mask is the new
+        token's row of the mask over all Tp+1 positions."""
         if attention_mask is not None or token_type_ids is not None or position_ids is not None or input_embeddings is not None:
             raise NotImplementedError('attention_mask/token_type_ids/position_ids/input_embeddings are never used by the CLI path')
         x = self._ids(inputs)
         past_len, past_ptrs, keep = 0, None, []
         if past is not None:
-            if training:
-                raise NotImplementedError('training=True together with `past` is not supported')
             x = np.ascontiguousarray(x[:, -1:])                                  # transformer.py:735-737
             past = list(past)
             if len(past) != self.decoder_layers_count:

@@ -140,7 +140,8 @@ int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logi
  *   ids of x are the tokens at positions past_len .. past_len+T-1 (the reference passes the last one, :735-737), their keys
  *   and values are appended to `past` (:423-426) and logits_out is [B,T,V]; cmp_present_get then takes T' = past_len + T.
  *   training != 0: dropout active (transformer.py:916-917 calls self(x, training=True)), masks from the model's seed and
- *   optimizer iteration like a train step's.  Not together with past. */
+ *   optimizer iteration like a train step's; with past, the attention-probability mask of a new token is its row of the
+ *   mask over all past_len + T positions. */
 int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                 float* logits_out);
 /* presents[layer] of the LAST forward pass (Transformer.call's second result, transformer.py:797-806, 820-821):

@@ -96,9 +96,11 @@ def dropout_keep_rows(seed, stream, nrows, ncols, p, row0=0):
     return x >= thr
 
 
-def dropout_keep_attn(seed, stream, BH, T, p):
-    """Attention-probability mask [BH, T(query), T(key)]."""
-    return dropout_keep_rows(seed, stream, BH * T, T, p).reshape(BH, T, T)
+def dropout_keep_attn(seed, stream, BH, T, p, past_len=0):
+    """Attention-probability mask [BH, T(query), past_len + T(key)]: the last T rows of the square mask over past_len + T
+    positions (with `past`, transformer.py:423-426, the T new queries sit at positions past_len .. past_len + T - 1)."""
+    Tt = past_len + T
+    return dropout_keep_rows(seed, stream, BH * Tt, Tt, p).reshape(BH, Tt, Tt)[:, past_len:, :]
 
 
 def dropout_stream(step, layer, site):
@@ -204,9 +206,9 @@ class OracleTransformer:
     def _dropout(self, x, p, step, layer, site, training):
         if not training or p <= 0.0:
             return x, None
-        if site == 1:      # attention probabilities [B,H,T,T]
+        if site == 1:      # attention probabilities [B,H,T,past_len+T]
             keep = dropout_keep_attn(self.seed, dropout_stream(step, layer, site), x.shape[0] * x.shape[1],
-                                     x.shape[2], p).reshape(x.shape)
+                                     x.shape[2], p, past_len=x.shape[3] - x.shape[2]).reshape(x.shape)
         else:
             keep = dropout_keep_rows(self.seed, dropout_stream(step, layer, site), x.size // x.shape[-1],
                                      x.shape[-1], p).reshape(x.shape)

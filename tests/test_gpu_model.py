@@ -281,6 +281,28 @@ def test_call_training_true_applies_the_train_step_dropout(dtype, tol):
     m.close()
 
 
+def test_call_training_true_with_past_matches_oracle():
+    """Transformer.call(inputs, past=presents, training=True) (transformer.py:696-833 allows the combination): dropout on the new
+    token's embedding, on its row of the attention probabilities over all past+1 positions, and on both residual branches."""
+    V, E, H, L, W, T, B = 390, 64, 4, 2, 48, 20, 2
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=23, stddev=0.1).items()}
+    x, _ = O.synthetic_batch(np.random.default_rng(9), V, B, T)
+    ocfg = O.Config(V, E, W, L, H, attention_dropout_rate=0.2, residual_dropout_rate=0.1)
+    orc = O.OracleTransformer(ocfg, params, seed=77)
+    m = make_model((V, E, H, L, W, T, B), params, "fp32", p_attn=0.2, p_resid=0.1, seed=77)
+    _, opast, _ = orc.forward(x[:, :9])
+    for t in range(9, 14):
+        past = [np.array(p, dtype=np.float32) for p in opast]
+        lg, pres = m(x[:, :t + 1], past=past, training=True)       # only the last token is used (:735-737)
+        olg, _, _ = orc.forward(x[:, t:t + 1], past=opast, training=True, step=0)
+        assert lg.shape == (B, 1, V) and pres[0].shape == (2, B, H, t + 1, E // H)
+        assert np.abs(lg - olg).max() <= 1e-4 * max(1.0, np.abs(olg).max()), t
+        off, _ = m(x[:, :t + 1], past=past)
+        assert np.abs(off - olg).max() > 1e-3                      # and it differs from the dropout-free call on the same past
+        _, opast, _ = orc.forward(x[:, t:t + 1], past=opast)        # next position: dropout-free presents
+    m.close()
+
+
 def test_ids_out_of_range_are_rejected_everywhere():
     """Every entry point refuses token ids outside [0, V): host paths before anything is launched, the device-pointer train
     step by a device-side clamp + count that cmp_train_metrics reports (evaluate / loss_and_grads / step_device)."""
