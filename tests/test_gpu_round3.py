@@ -303,3 +303,60 @@ def test_decode_state_is_reused_and_follows_the_weights():
     want.train_step(x, y, 1e-2, training=False)
     assert m.generate(prompt, 12, temperature=0.0, mode="kv").tolist() == want.generate_kv(prompt, 12)
     m.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# edge shapes: the smallest model the kernels accept, one token, a full window, colliding ids, boundary ids
+# ------------------------------------------------------------------------------------------------------------------
+EDGE_CASES = [
+    # V,  E, H, L,  W,  T, B, ids
+    (5, 16, 1, 1, 4, 1, 1, "random"),          # one token, one row, one head of 16
+    (390, 32, 2, 1, 8, 8, 1, "random"),        # T == W: the position table is used to its last row
+    (7, 64, 4, 2, 16, 3, 5, "same"),           # every position holds the same id: all embedding-gradient rows collide
+    (390, 64, 2, 2, 40, 33, 3, "boundary"),    # ids 0 and V-1 only; T not a multiple of any tile
+    (2, 32, 1, 1, 6, 5, 2, "random"),          # two-word vocabulary
+]
+
+
+@pytest.mark.parametrize("case", EDGE_CASES, ids=lambda c: "V%d-E%d-H%d-L%d-W%d-T%d-B%d-%s" % c)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_edge_shapes_match_the_oracle(case, dtype):
+    """Loss, accuracy and every parameter gradient of one step (dropout off) against the float64 restatement at the corner
+    shapes; then two optimizer steps and a greedy continuation on the same model."""
+    from composer_amd import _lib
+    from test_gpu_model import make_model
+    V, E, H, L, W, T, B, kind = case
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=31, stddev=0.2).items()}
+    rng = np.random.default_rng(17)
+    if kind == "same":
+        x = np.full((B, T), 3, np.int32); y = np.full((B, T), 3, np.int32)
+    elif kind == "boundary":
+        x = rng.choice(np.array([0, V - 1], np.int32), size=(B, T)); y = rng.choice(np.array([0, V - 1], np.int32), size=(B, T))
+    else:
+        x, y = O.synthetic_batch(rng, V, B, T)
+    ocfg = O.Config(V, E, W, L, H)
+    orc = O.OracleTransformer(ocfg, params, emulate_bf16=(dtype == "bf16"))
+    loss, acc, G, _ = orc.loss_and_grads(x, y, training=False)
+    m = make_model((V, E, H, L, W, T, B), params, dtype)
+    if dtype == "fp32" and T + 2 <= W:             # greedy continuation on identical weights (before any optimizer step)
+        prompt = x[0, :T]
+        assert m.generate(prompt, 3, temperature=0.0, mode="kv").tolist() == list(orc.generate_kv(prompt, 3))
+        assert m.generate(prompt, 3, temperature=0.0, mode="literal").tolist() == list(orc.generate_literal(prompt, 3))
+    logits, _ = m(x)
+    want, _, _ = orc.forward(x)
+    tol = 1e-4 if dtype == "fp32" else 3e-2
+    assert np.abs(logits - want).max() <= tol * max(1.0, np.abs(want).max())
+    l2, a2 = m.loss_and_grads(x, y)
+    assert abs(l2 - loss) <= (1e-5 if dtype == "fp32" else 2e-2) * abs(loss)
+    if dtype == "fp32":
+        assert abs(a2 - acc) < 1e-6
+    worst = 0.0
+    for n in m.parameter_names:
+        gr = m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64)
+        worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-12))
+    assert worst <= (5e-4 if dtype == "fp32" else 3e-2), worst
+    for s in range(2):
+        lo, _ = orc.train_step(x, y, 1e-3, training=False)
+        lm, _ = m.train_step(x, y, 1e-3)
+        assert abs(lm - lo) <= (1e-4 if dtype == "fp32" else 2e-2) * abs(lo), (s, lm, lo)
+    m.close()
