@@ -321,7 +321,7 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ ws, float* __re
 // softmax cross-entropy forward + backward in one pass     transformer.py:888,918,924-926
 // one wave per row.  loss_row = logsumexp(z) - z[y];  dz = (softmax(z) - onehot(y)) * inv_n
 // =================================================================================================
-#define XENT_MAXI 8   // vocab <= 512 columns (incl. padding)
+#define XENT_MAXI 8   // register-resident rows: vocab <= 512 columns (incl. padding); wider rows take softmax_xent_wide_kernel
 template <typename T>
 __global__ void softmax_xent_kernel(const float* __restrict__ z, int ldz, const int32_t* __restrict__ y,
                                     T* __restrict__ dz, float* __restrict__ row_loss,
@@ -382,6 +382,53 @@ __global__ void softmax_xent_kernel(const float* __restrict__ z, int ldz, const 
         }
         if (lane == 0) {
             row_loss[row] = lse - zy2;
+            row_correct[row] = (arg == yy) ? 1 : 0;
+        }
+    }
+}
+
+// the same for any vocabulary size (ldz > 64 * XENT_MAXI): three passes over the row, which stays in L1/L2 between them
+template <typename T>
+__global__ void softmax_xent_wide_kernel(const float* __restrict__ z, int ldz, const int32_t* __restrict__ y,
+                                         T* __restrict__ dz, float* __restrict__ row_loss,
+                                         int32_t* __restrict__ row_correct, int rows, int V, float inv_n) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+        const float* zr = z + (int64_t)row * ldz;
+        float mx = -INFINITY;
+        int arg = 0x7fffffff;
+        for (int c = lane; c < V; c += 64) {
+            const float v = zr[c];
+            if (v > mx) {      // strict >: the lowest index within the lane (columns ascend)
+                mx = v;
+                arg = c;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float om = __shfl_xor(mx, o);
+            int oa = __shfl_xor(arg, o);
+            if (om > mx || (om == mx && oa < arg)) {
+                mx = om;
+                arg = oa;
+            }
+        }
+        float s = 0.f;
+        for (int c = lane; c < V; c += 64) s += expf(zr[c] - mx);
+        s = wave_sum(s);
+        const float lse = mx + logf(s);
+        const int yy = y[row];
+        if (dz) {
+            T* dr = dz + (int64_t)row * ldz;
+            for (int c = lane; c < ldz; c += 64) {
+                float g = 0.f;
+                if (c < V) g = (expf(zr[c] - lse) - (c == yy ? 1.0f : 0.0f)) * inv_n;
+                dr[c] = from_f32<T>(g);
+            }
+        }
+        if (lane == 0) {
+            row_loss[row] = lse - zr[yy];
             row_correct[row] = (arg == yy) ? 1 : 0;
         }
     }
@@ -661,11 +708,16 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
 
 extern "C" int cmp_k_softmax_xent(void* stream, const float* logits, int ldz, const int32_t* y, void* dlogits,
                                   float* row_loss, int32_t* row_correct, int rows, int V, float inv_n, int dtype) {
-    CMP_REQUIRE(ldz <= 64 * XENT_MAXI && V <= ldz, "softmax_xent: V=%d ldz=%d unsupported (max %d)", V, ldz, 64 * XENT_MAXI);
+    CMP_REQUIRE(V > 0 && V <= ldz, "softmax_xent: V=%d ldz=%d", V, ldz);
     if (rows == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = std::min(cdiv(rows, 4), 8192);
-    if (dtype == CMP_BF16)
+    if (ldz > 64 * XENT_MAXI) {
+        if (dtype == CMP_BF16)
+            softmax_xent_wide_kernel<bf16_t><<<grid, 256, 0, s>>>(logits, ldz, y, (bf16_t*)dlogits, row_loss, row_correct, rows, V, inv_n);
+        else
+            softmax_xent_wide_kernel<float><<<grid, 256, 0, s>>>(logits, ldz, y, (float*)dlogits, row_loss, row_correct, rows, V, inv_n);
+    } else if (dtype == CMP_BF16)
         softmax_xent_kernel<bf16_t><<<grid, 256, 0, s>>>(logits, ldz, y, (bf16_t*)dlogits, row_loss, row_correct, rows, V, inv_n);
     else
         softmax_xent_kernel<float><<<grid, 256, 0, s>>>(logits, ldz, y, (float*)dlogits, row_loss, row_correct, rows, V, inv_n);

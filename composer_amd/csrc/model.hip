@@ -237,7 +237,6 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     CMP_REQUIRE(E % 8 == 0, "model_create: embedding_size %d must be a multiple of 8", E);
     const int D = E / H;
     CMP_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, "model_create: head size %d unsupported (16/32/64/128)", D);
-    CMP_REQUIRE(V <= 512, "model_create: vocab_size %d > 512 unsupported by the fused softmax-xent kernel", V);
     CMP_REQUIRE(cfg->dtype == CMP_FP32 || cfg->dtype == CMP_BF16, "model_create: bad dtype %d", cfg->dtype);
     CMP_REQUIRE(L < 64, "model_create: at most 63 layers");
     HIP_CHECK(hipSetDevice(ctx->device));

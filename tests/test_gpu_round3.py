@@ -315,6 +315,7 @@ EDGE_CASES = [
     (7, 64, 4, 2, 16, 3, 5, "same"),           # every position holds the same id: all embedding-gradient rows collide
     (390, 64, 2, 2, 40, 33, 3, "boundary"),    # ids 0 and V-1 only; T not a multiple of any tile
     (2, 32, 1, 1, 6, 5, 2, "random"),          # two-word vocabulary
+    (1384, 32, 2, 1, 12, 5, 2, "random"),      # a vocabulary wider than the register-resident loss kernel's 512 columns
 ]
 
 
@@ -360,3 +361,51 @@ def test_edge_shapes_match_the_oracle(case, dtype):
         lm, _ = m.train_step(x, y, 1e-3)
         assert abs(lm - lo) <= (1e-4 if dtype == "fp32" else 2e-2) * abs(lo), (s, lm, lo)
     m.close()
+
+
+def _random_small_configs(n, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        D = int(rng.choice([16, 32, 64, 128]))
+        H = int(rng.choice([1, 2, 3, 4, 6]))
+        E = D * H
+        if E > 384:
+            continue
+        L = int(rng.integers(1, 4))
+        W = int(rng.integers(2, 70))
+        T = int(rng.integers(1, W + 1))
+        B = int(rng.integers(1, 6))
+        V = int(rng.choice([3, 17, 390, 1000]))
+        out.append((V, E, H, L, W, T, B, bool(rng.integers(0, 2)), int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_small_configs(24), ids=lambda c: "V%d-E%d-H%d-L%d-W%d-T%d-B%d-drop%d-s%d" % c)
+def test_random_small_shapes_match_the_oracle(cfg):
+    """A seeded sweep of small model shapes (head sizes 16..128, 1..6 heads, 1..3 blocks, ragged T and B, four vocabulary sizes),
+    half of them with dropout on (shared counter-hash masks): fp32 loss and every gradient against the float64 restatement, and
+    the bf16 kernels against the restatement rounded where they round."""
+    from composer_amd import _lib
+    from test_gpu_model import make_model
+    V, E, H, L, W, T, B, drop, seed = cfg
+    p = 0.15 if drop else 0.0
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=seed % 1000, stddev=0.1).items()}
+    rng = np.random.default_rng(seed)
+    for k in params:
+        if k.endswith(("gamma", "beta", "bias")):
+            params[k] = (params[k] + 0.05 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    x, y = O.synthetic_batch(rng, V, B, T)
+    ocfg = O.Config(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p)
+    for dtype in ("fp32", "bf16"):
+        orc = O.OracleTransformer(ocfg, params, seed=seed % 97, emulate_bf16=(dtype == "bf16"))
+        loss, acc, G, _ = orc.loss_and_grads(x, y, training=drop, step=0)
+        m = make_model((V, E, H, L, W, T, B), params, dtype, p_attn=p, p_resid=p, seed=seed % 97)
+        l2, a2 = m.loss_and_grads(x, y)
+        assert abs(l2 - loss) <= (2e-5 if dtype == "fp32" else 2e-2) * abs(loss), (dtype, l2, loss)
+        worst = 0.0
+        for n in m.parameter_names:
+            gr = m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64)
+            worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-12))
+        assert worst <= (5e-4 if dtype == "fp32" else 4e-2), (dtype, worst)
+        m.close()
