@@ -1723,9 +1723,14 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
 
 extern "C" int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, int scale,
                               int dtype, float p_drop, uint64_t seed, uint32_t rng_stream) {
+    return attn_fwd_run(stream, qkv, o, lse, B, T, H, D, scale ? 1.0f / sqrtf((float)D) : 1.0f, dtype, p_drop, seed, rng_stream);
+}
+
+// sc: the factor on q.k (the model driver passes 1/sqrt(E/H) of the reference's head size, which may be smaller than D: zero-padded heads)
+int attn_fwd_run(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, float sc, int dtype, float p_drop,
+                 uint64_t seed, uint32_t rng_stream) {
     if (B * T == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
-    float sc = scale ? 1.0f / sqrtf((float)D) : 1.0f;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
     if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
     else { DISPATCH_D(float, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
@@ -1745,15 +1750,15 @@ extern "C" int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, cons
                               float p_drop, uint64_t seed, uint32_t rng_stream) {
     float* bias_grad = t_attn_bias_next;
     t_attn_bias_next = nullptr;
-    return attn_bwd_run(stream, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, D, scale, dtype, p_drop, seed, rng_stream, bias_grad);
+    return attn_bwd_run(stream, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, D, scale ? 1.0f / sqrtf((float)D) : 1.0f, dtype, p_drop, seed,
+                        rng_stream, bias_grad);
 }
 
 int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
-                 int B, int T, int H, int D, int scale, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
+                 int B, int T, int H, int D, float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
                  float* bias_grad) {
     if (B * T == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
-    float sc = scale ? 1.0f / sqrtf((float)D) : 1.0f;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
     if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }
     else { DISPATCH_D(float, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }

@@ -65,8 +65,10 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
              void* C, int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
              int splitk, float p_drop, uint64_t seed, uint32_t rng_stream, int flags, const GemmExtra& ex);
 int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
-                 int B, int T, int H, int D, int scale, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
+                 int B, int T, int H, int D, float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
                  float* bias_grad);
+int attn_fwd_run(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, float sc, int dtype, float p_drop,
+                 uint64_t seed, uint32_t rng_stream);
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

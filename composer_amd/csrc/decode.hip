@@ -744,10 +744,10 @@ static int launch_gemv2(hipStream_t s, int act, int in_mode, const float* x, con
 static int launch_attn2(hipStream_t s, cmp_model* m, DecodeState* d, const DecLayerW& w, float scale) {
     dim3 grid(m->H, ATT_SPLITS);
     switch (m->D) {
-        case 16: dec_attn2_kernel<16><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
-        case 32: dec_attn2_kernel<32><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
-        case 64: dec_attn2_kernel<64><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
-        default: dec_attn2_kernel<128><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->E, m->W, scale); break;
+        case 16: dec_attn2_kernel<16><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->Ea, m->W, scale); break;
+        case 32: dec_attn2_kernel<32><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->Ea, m->W, scale); break;
+        case 64: dec_attn2_kernel<64><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->Ea, m->W, scale); break;
+        default: dec_attn2_kernel<128><<<grid, 256, 0, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, m->Ea, m->W, scale); break;
     }
     KERNEL_CHECK();
     return CMP_OK;
@@ -759,17 +759,17 @@ static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
     // 3 LN2+c_fc, 4 mlp c_proj, 5 logits, 6 sampler are left out of the captured chain
     int skip = 0;
     { const char* e = getenv("COMPOSER_DECODE_DIAG_SKIP"); if (e) skip = atoi(e); }
-    const int E = m->E, L = m->L;
+    const int E = m->E, Ea = m->Ea, L = m->L;
     const bool ln = m->cfg.use_layer_norm != 0;
     const float eps = m->cfg.ln_eps;
-    const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->D) : 1.0f;
+    const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->Dl) : 1.0f;
     for (int i = 0; i < L; i++) {
         const LayerOff& o = m->lo[i];
         const DecLayerW& w = d->lw[i];
         if (!(skip & 1)) CHECK_RC(launch_gemv2(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
-                              d->qkv, d->u, E, 3 * E, m->D));
+                              d->qkv, d->u, E, 3 * Ea, m->D));
         if (!(skip & 2)) CHECK_RC(launch_attn2(s, m, d, w, scale));
-        if (!(skip & 4)) CHECK_RC(launch_gemv2(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, E, E, m->D));
+        if (!(skip & 4)) CHECK_RC(launch_gemv2(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, Ea, E, m->D));
         if (!(skip & 8)) CHECK_RC(launch_gemv2(s, 1, ln ? 1 : 0, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
                               nullptr, E, 4 * E, m->D));
         if (!(skip & 16)) CHECK_RC(launch_gemv2(s, 0, 0, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E, m->D));
@@ -786,19 +786,19 @@ static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
 static int enqueue_token_step(cmp_model* m, DecodeState* d) {
     if (!d->v1) return enqueue_token_step2(m, d);
     hipStream_t s = m->ctx->stream;
-    const int E = m->E, L = m->L;
+    const int E = m->E, Ea = m->Ea, L = m->L;
     const bool ln = m->cfg.use_layer_norm != 0;
     const float eps = m->cfg.ln_eps;
-    const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->D) : 1.0f;
+    const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->Dl) : 1.0f;
     for (int i = 0; i < L; i++) {
         const LayerOff& o = m->lo[i];
         const DecLayerW& w = d->lw[i];
         CHECK_RC(launch_gemv(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
-                             d->qkv, d->u, E, 3 * E, m->D));
+                             d->qkv, d->u, E, 3 * Ea, m->D));
         size_t smem = (size_t)(m->D + 8 + (m->W + ATT_SPLITS - 1) / ATT_SPLITS + 4 + 256) * 4;
-        dec_attn_kernel<<<dim3(m->H, ATT_SPLITS), 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, E, m->D, m->W, scale);
+        dec_attn_kernel<<<dim3(m->H, ATT_SPLITS), 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, Ea, m->D, m->W, scale);
         KERNEL_CHECK();
-        CHECK_RC(launch_gemv(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, E, E, m->D));
+        CHECK_RC(launch_gemv(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, Ea, E, m->D));
         CHECK_RC(launch_gemv(s, 1, ln ? 1 : 0, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
                              nullptr, E, 4 * E, m->D));
         CHECK_RC(launch_gemv(s, 0, 0, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E, m->D));
@@ -842,13 +842,13 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     d->temperature = temperature;
     d->seed = seed;
     d->cap = 1 << 16;
-    const int E = m->E, L = m->L, W = m->W;
+    const int E = m->E, Ea = m->Ea, L = m->L, W = m->W;
     if (!d->built) {
         CHECK_RC(dalloc(d, &d->st, sizeof(DecState)));
         CHECK_RC(dalloc(d, &d->ids, (size_t)d->cap * 4));
         CHECK_RC(dalloc(d, &d->x, (size_t)E * 4));
         CHECK_RC(dalloc(d, &d->u, (size_t)E * 4));
-        CHECK_RC(dalloc(d, &d->qkv, (size_t)3 * E * 4));
+        CHECK_RC(dalloc(d, &d->qkv, (size_t)3 * Ea * 4));
         CHECK_RC(dalloc(d, &d->att, (size_t)m->H * ATT_SPLITS * PSTRIDE(m->D) * 4));  // split-key attention partials
         CHECK_RC(dalloc(d, &d->r, (size_t)E * 4));
         CHECK_RC(dalloc(d, &d->g, (size_t)4 * E * 4));
@@ -856,12 +856,12 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
         d->lw.resize(L);
         for (int i = 0; i < L; i++) {
             DecLayerW& w = d->lw[i];
-            CHECK_RC(dalloc(d, &w.attn_wT, (size_t)3 * E * E * 4));
-            CHECK_RC(dalloc(d, &w.proj_wT, (size_t)E * E * 4));
+            CHECK_RC(dalloc(d, &w.attn_wT, (size_t)3 * Ea * E * 4));
+            CHECK_RC(dalloc(d, &w.proj_wT, (size_t)Ea * E * 4));
             CHECK_RC(dalloc(d, &w.fc_wT, (size_t)4 * E * E * 4));
             CHECK_RC(dalloc(d, &w.pr_wT, (size_t)4 * E * E * 4));
-            CHECK_RC(dalloc(d, &w.kc, (size_t)W * E * 4));
-            CHECK_RC(dalloc(d, &w.vc, (size_t)W * E * 4));
+            CHECK_RC(dalloc(d, &w.kc, (size_t)W * Ea * 4));
+            CHECK_RC(dalloc(d, &w.vc, (size_t)W * Ea * 4));
         }
     }
     if (d->weights_version != m->param_version) {
@@ -872,8 +872,8 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
                 dim3 grid(cdiv(N, 32), cdiv(K, 32));
                 transpose_kernel<<<grid, 256, 0, s>>>(in, out, K, N);
             };
-            tr(m->P + o.attn_w, w.attn_wT, E, 3 * E);
-            tr(m->P + o.proj_w, w.proj_wT, E, E);
+            tr(m->P + o.attn_w, w.attn_wT, E, 3 * Ea);
+            tr(m->P + o.proj_w, w.proj_wT, Ea, E);
             tr(m->P + o.fc_w, w.fc_wT, E, 4 * E);
             tr(m->P + o.pr_w, w.pr_wT, 4 * E, E);
             KERNEL_CHECK();
@@ -886,17 +886,17 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     CHECK_RC(model_forward(m, m->x_dev, 1, P, false, 0));
     if (mode == CMP_DECODE_KV) {
         for (int i = 0; i < L; i++) {
-            int grid = cdiv(P * E, 256);
+            int grid = cdiv(P * Ea, 256);
             if (d->v1) {
                 if (m->dtype == CMP_BF16)
-                    cache_fill_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+                    cache_fill_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
                 else
-                    cache_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+                    cache_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
             } else {
                 if (m->dtype == CMP_BF16)
-                    cache_fill2_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+                    cache_fill2_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
                 else
-                    cache_fill2_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, E, m->H, m->D, W);
+                    cache_fill2_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
             }
             KERNEL_CHECK();
         }

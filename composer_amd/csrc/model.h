@@ -46,9 +46,13 @@ struct cmp_ctx {
 struct ParamInfo {
     std::string name;
     int rank;
-    int64_t shape[4];
-    int64_t numel;
+    int64_t shape[4];          // the reference's (logical) shape
+    int64_t numel;             // logical element count
     int64_t offset;
+    // head-size padding (cmp_model::Dl < D): 0 stored as is; 1 the last dimension is [3][H][Dl] stored as [3][H][D] (c_attn weight
+    // and bias); 2 the first dimension is [H][Dl] stored as [H][D] (attention c_proj weight).  Padding entries are zero, stay zero.
+    int pad = 0;
+    int64_t store = 0;         // stored element count
 };
 
 struct LayerOff {   // element offsets into the flat buffers
@@ -70,6 +74,11 @@ struct cmp_model {
     cmp_ctx* ctx = nullptr;
     cmp_model_cfg cfg;
     int V, E, W, L, H, D, ldz;
+    // Head sizes other than 16 / 32 / 64 / 128 (E / H = Dl) run on the next supported size D with zero-filled columns: the c_attn
+    // output is [.., 3 * Ea], Ea = H * D, head h of q / k / v at h * D with Dl live columns; the attention kernels see (H, D) and
+    // the scale 1/sqrt(Dl); zero columns of q, k, v leave every score and every output value unchanged and their gradients are
+    // exactly zero.  Parameters, presents and `past` keep the reference's shapes at the ABI.  Dl == D: Ea == E, nothing changes.
+    int Dl = 0, Ea = 0;
     int dtype;
     size_t es;                 // activation element size
     std::vector<ParamInfo> params;

@@ -213,7 +213,7 @@ extern "C" int cmp_dp_allreduce_test(cmp_ctx* c, float* host_inout, int n) {
 // -------------------------------------------------------------------------------------------------
 // model construction
 // -------------------------------------------------------------------------------------------------
-static int64_t add_param(cmp_model* m, const std::string& name, int rank, int64_t d0, int64_t d1) {
+static int64_t add_param(cmp_model* m, const std::string& name, int rank, int64_t d0, int64_t d1, int pad = 0) {
     ParamInfo p;
     p.name = name;
     p.rank = rank;
@@ -221,8 +221,12 @@ static int64_t add_param(cmp_model* m, const std::string& name, int rank, int64_
     p.shape[1] = d1;
     p.shape[2] = p.shape[3] = 1;
     p.numel = d0 * (rank > 1 ? d1 : 1);
+    p.pad = (m->Dl == m->D) ? 0 : pad;
+    p.store = p.numel;
+    if (p.pad == 1) p.store = d0 * 3 * m->Ea;          // [d0][3][H][D]
+    if (p.pad == 2) p.store = (int64_t)m->Ea * d1;     // [H][D][d1]
     p.offset = m->total;
-    m->total += (p.numel + 7) / 8 * 8;
+    m->total += (p.store + 7) / 8 * 8;
     m->index[name] = (int)m->params.size();
     m->params.push_back(p);
     return p.offset;
@@ -235,15 +239,16 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     CMP_REQUIRE(V > 0 && E > 0 && W > 0 && L > 0 && H > 0, "model_create: sizes must be positive");
     CMP_REQUIRE(E % H == 0, "model_create: embedding_size %d not divisible by heads %d (transformer.py:255)", E, H);
     CMP_REQUIRE(E % 8 == 0, "model_create: embedding_size %d must be a multiple of 8", E);
-    const int D = E / H;
-    CMP_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, "model_create: head size %d unsupported (16/32/64/128)", D);
+    const int Dl = E / H;
+    CMP_REQUIRE(Dl <= 128, "model_create: head size %d unsupported (at most 128)", Dl);
+    const int D = Dl <= 16 ? 16 : (Dl <= 32 ? 32 : (Dl <= 64 ? 64 : 128));     // the attention kernels' head sizes; Dl < D: zero-padded columns
     CMP_REQUIRE(cfg->dtype == CMP_FP32 || cfg->dtype == CMP_BF16, "model_create: bad dtype %d", cfg->dtype);
     CMP_REQUIRE(L < 64, "model_create: at most 63 layers");
     HIP_CHECK(hipSetDevice(ctx->device));
     cmp_model* m = new cmp_model();
     m->ctx = ctx;
     m->cfg = *cfg;
-    m->V = V; m->E = E; m->W = W; m->L = L; m->H = H; m->D = D;
+    m->V = V; m->E = E; m->W = W; m->L = L; m->H = H; m->D = D; m->Dl = Dl; m->Ea = H * D;
     m->ldz = (V + 63) / 64 * 64;
     m->dtype = cfg->dtype;
     m->es = dtype_size(cfg->dtype);
@@ -256,9 +261,9 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
         o.begin = m->total;
         o.ln1_g = add_param(m, p + "ln_1/gamma", 1, E, 1);
         o.ln1_b = add_param(m, p + "ln_1/beta", 1, E, 1);
-        o.attn_w = add_param(m, p + "attn/c_attn/weight", 2, E, 3 * E);
-        o.attn_b = add_param(m, p + "attn/c_attn/bias", 2, 1, 3 * E);
-        o.proj_w = add_param(m, p + "attn/c_proj/weight", 2, E, E);
+        o.attn_w = add_param(m, p + "attn/c_attn/weight", 2, E, 3 * E, 1);
+        o.attn_b = add_param(m, p + "attn/c_attn/bias", 2, 1, 3 * E, 1);
+        o.proj_w = add_param(m, p + "attn/c_proj/weight", 2, E, E, 2);
         o.proj_b = add_param(m, p + "attn/c_proj/bias", 2, 1, E);
         o.ln2_g = add_param(m, p + "ln_2/gamma", 1, E, 1);
         o.ln2_b = add_param(m, p + "ln_2/beta", 1, E, 1);
@@ -287,8 +292,8 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
         std::vector<WDesc> wd;
         for (int i = 0; i < m->L; i++) {
             const LayerOff& o = m->lo[i];
-            wd.push_back({o.attn_w, m->E, 3 * m->E});
-            wd.push_back({o.proj_w, m->E, m->E});
+            wd.push_back({o.attn_w, m->E, 3 * m->Ea});
+            wd.push_back({o.proj_w, m->Ea, m->E});
             wd.push_back({o.fc_w, m->E, 4 * m->E});
             wd.push_back({o.pr_w, 4 * m->E, m->E});
         }
@@ -342,6 +347,31 @@ extern "C" int cmp_param_info(cmp_model* m, int i, const char** name, int* rank,
     if (numel) *numel = p.numel;
     return CMP_OK;
 }
+// logical <-> stored layout of the three head-padded tensors of a block (ParamInfo::pad); to_store: logical -> stored (the
+// caller zero-fills `st`), else stored -> logical
+static void pad_copy(const cmp_model* m, const ParamInfo& p, float* st, float* logical, bool to_store) {
+    const int H = m->H, D = m->D, Dl = m->Dl, E = m->E, Ea = m->Ea;
+    if (p.pad == 1) {                       // rows x [3][H][Dl]  <->  rows x [3][H][D]
+        const int64_t rows = p.numel / (3 * E);
+        for (int64_t r = 0; r < rows; r++)
+            for (int part = 0; part < 3; part++)
+                for (int h = 0; h < H; h++)
+                    for (int d = 0; d < Dl; d++) {
+                        float& a = st[r * 3 * Ea + (int64_t)part * Ea + h * D + d];
+                        float& b = logical[r * 3 * E + (int64_t)part * E + h * Dl + d];
+                        if (to_store) a = b; else b = a;
+                    }
+    } else {                                // [H][Dl] x cols  <->  [H][D] x cols
+        const int64_t cols = p.shape[1];
+        for (int h = 0; h < H; h++)
+            for (int d = 0; d < Dl; d++)
+                for (int64_t c = 0; c < cols; c++) {
+                    float& a = st[((int64_t)h * D + d) * cols + c];
+                    float& b = logical[((int64_t)h * Dl + d) * cols + c];
+                    if (to_store) a = b; else b = a;
+                }
+    }
+}
 static float* kind_buf(cmp_model* m, int kind) {
     switch (kind) {
         case 0: return m->P;
@@ -361,6 +391,12 @@ extern "C" int cmp_param_get(cmp_model* m, const char* name, int kind, float* ho
     CMP_REQUIRE(b, "param_get: bad kind %d", kind);
     HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     HIP_CHECK(hipStreamSynchronize(m->ctx->comm_stream));
+    if (p.pad) {
+        std::vector<float> st((size_t)p.store);
+        HIP_CHECK(hipMemcpy(st.data(), b + p.offset, (size_t)p.store * 4, hipMemcpyDeviceToHost));
+        pad_copy(m, p, st.data(), host, false);
+        return CMP_OK;
+    }
     HIP_CHECK(hipMemcpy(host, b + p.offset, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return CMP_OK;
 }
@@ -373,10 +409,16 @@ extern "C" int cmp_param_set(cmp_model* m, const char* name, int kind, const flo
     float* b = kind_buf(m, kind);
     CMP_REQUIRE(b, "param_set: bad kind %d", kind);
     HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
-    HIP_CHECK(hipMemcpy(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice));
+    if (p.pad) {
+        std::vector<float> st((size_t)p.store, 0.f);
+        pad_copy(m, p, st.data(), const_cast<float*>(host), true);
+        HIP_CHECK(hipMemcpy(b + p.offset, st.data(), (size_t)p.store * 4, hipMemcpyHostToDevice));
+    } else {
+        HIP_CHECK(hipMemcpy(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice));
+    }
     if (kind == 0) m->param_version += 1;
     if (kind == 0 && m->S) {
-        int64_t n8 = (p.numel + 7) / 8 * 8;
+        int64_t n8 = (p.store + 7) / 8 * 8;
         CHECK_RC(launch_cast_bf16(m->ctx->stream, m->P + p.offset, m->S + p.offset, n8));
         HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     }
@@ -416,8 +458,8 @@ int ensure_workspace(cmp_model* m, int B, int T) {
     for (int i = 0; i < L; i++) {
         LayerAct& a = m->act[i];
         if (ln) CHECK_RC(dev_alloc(m, &a.u, (size_t)M * E * es)); else a.u = m->xs[i];
-        CHECK_RC(dev_alloc(m, &a.qkv, (size_t)M * 3 * E * es));
-        CHECK_RC(dev_alloc(m, &a.att, (size_t)M * E * es));
+        CHECK_RC(dev_alloc(m, &a.qkv, (size_t)M * 3 * m->Ea * es));
+        CHECK_RC(dev_alloc(m, &a.att, (size_t)M * m->Ea * es));
         CHECK_RC(dev_alloc(m, &a.r, (size_t)M * E * es));
         if (ln) CHECK_RC(dev_alloc(m, &a.n, (size_t)M * E * es)); else a.n = a.r;
         CHECK_RC(dev_alloc(m, &a.fc, (size_t)M * 4 * E * es));
@@ -440,16 +482,16 @@ int ensure_workspace(cmp_model* m, int B, int T) {
     CHECK_RC(dev_alloc(m, &m->y_dev, (size_t)M * 4));
     CHECK_RC(dev_alloc(m, &m->dx, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->dr, (size_t)M * E * es));
-    CHECK_RC(dev_alloc(m, &m->tmpE, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->tmpE, (size_t)M * m->Ea * es));          // [M, E] gradients and the [M, Ea] attention-output gradient
     CHECK_RC(dev_alloc(m, &m->dmask, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->dfc, (size_t)M * 4 * E * es));
-    CHECK_RC(dev_alloc(m, &m->dqkv, (size_t)M * 3 * E * es));
+    CHECK_RC(dev_alloc(m, &m->dqkv, (size_t)M * 3 * m->Ea * es));
     {   // COMPOSER_DETERMINISTIC=1: no float atomics anywhere in the step -- split-K wgrads write per-split slabs and fold them
         // in a fixed order, the bias-gradient column sums and the LayerNorm parameter partials are folded by one thread per
         // column, the embedding scatter-add becomes a segmented gather.  Bitwise reproducible steps.
         const char* det = getenv("COMPOSER_DETERMINISTIC");
         if (det && det[0] == '1') {
-            m->slab_bytes = (int64_t)64 * E * E * 4 + (int64_t)64 * m->V * E * 4;
+            m->slab_bytes = (int64_t)16 * E * std::max(4 * E, 3 * m->Ea) * 4 + (int64_t)64 * m->V * E * 4;
             CHECK_RC(dev_alloc(m, &m->slab, (size_t)m->slab_bytes));
         }
     }
@@ -500,7 +542,7 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const bf16_t* __
 }
 static int refresh_transposed_weights(cmp_model* m) {
     if (!m->ST) return CMP_OK;
-    const int maxtiles = cdiv(4 * m->E, 32) * cdiv(m->E, 32);
+    const int maxtiles = std::max(cdiv(4 * m->E, 32) * cdiv(m->E, 32), cdiv(3 * m->Ea, 32) * cdiv(m->E, 32));   // [E,4E] or the head-padded [E,3Ea]
     transpose_weights_kernel<<<dim3(maxtiles, 4 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc);
     KERNEL_CHECK();
     return CMP_OK;
@@ -566,6 +608,9 @@ static int rows_copy(cmp_model* m, const void* src, void* dst, int B, int Tn, in
 // of act[i].qkv viewed as [B, past_len + T, 3E] by cmp_forward, the new rows are appended behind them, the causal attention
 // kernel runs over all past_len + T rows (the mask of transformer.py:290-301 for nd = T, ns = past_len + T is the last T
 // rows of the square one) and the T new output rows are taken out again.
+// transformer.py:340-343: w / sqrt(head size) -- the reference's head size E / H, whatever size the kernels run on
+static float attn_scale(const cmp_model* m) { return m->cfg.scale_attention ? 1.0f / sqrtf((float)m->Dl) : 1.0f; }
+
 int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool training, int64_t step, int past_len) {
     Range range_("composer.forward");
     hipStream_t s = m->ctx->stream;
@@ -574,7 +619,7 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         RoleGuard(cmp_model* mm) : m(mm) { m->gemm_role = 0; }
         ~RoleGuard() { m->gemm_role = -1; }
     } role_guard(m);
-    const int E = m->E, M = B * T, dt = m->dtype;
+    const int E = m->E, Ea = m->Ea, M = B * T, dt = m->dtype;
     const float pr = training ? m->cfg.resid_dropout : 0.f;
     const float pa = training ? m->cfg.attn_dropout : 0.f;
     const bool ln = m->cfg.use_layer_norm != 0;
@@ -593,14 +638,14 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         if (ln)   // transformer.py:583-584 -- the LN output REPLACES the residual stream
             CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[i], m->P + o.ln1_g, m->P + o.ln1_b, a.u, a.ln1_mean, a.ln1_rstd, M, E,
                                          m->cfg.ln_eps, dt));
-        CHECK_RC(gemm(m, 0, wt, M, 3 * E, E, a.u, E, W(o.attn_w), wt ? E : 3 * E, Tp ? m->dqkv : a.qkv, 3 * E, m->P + o.attn_b, 0,
+        CHECK_RC(gemm(m, 0, wt, M, 3 * Ea, E, a.u, E, W(o.attn_w), wt ? E : 3 * Ea, Tp ? m->dqkv : a.qkv, 3 * Ea, m->P + o.attn_b, 0,
                       nullptr, 0, nullptr, 0, 0, 1, 0.f, 0));
-        if (Tp) CHECK_RC(rows_copy(m, m->dqkv, a.qkv, B, T, 3 * E, T, 0, 3 * E, Tt, Tp, 3 * E));     // concat([past, new]) :423-426
-        CHECK_RC(cmp_k_attn_fwd(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, m->cfg.scale_attention, dt, pa, m->drop_seed(),
-                                drop_stream(step, i, 1)));
+        if (Tp) CHECK_RC(rows_copy(m, m->dqkv, a.qkv, B, T, 3 * Ea, T, 0, 3 * Ea, Tt, Tp, 3 * Ea));  // concat([past, new]) :423-426
+        CHECK_RC(attn_fwd_run(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, attn_scale(m), dt, pa, m->drop_seed(),
+                              drop_stream(step, i, 1)));
         const void* att = a.att;
-        if (Tp) { CHECK_RC(rows_copy(m, a.att, m->tmpE, B, T, E, Tt, Tp, E, T, 0, E)); att = m->tmpE; }
-        CHECK_RC(gemm(m, 0, wt, M, E, E, att, E, W(o.proj_w), E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
+        if (Tp) { CHECK_RC(rows_copy(m, a.att, m->tmpE, B, T, Ea, Tt, Tp, Ea, T, 0, Ea)); att = m->tmpE; }
+        CHECK_RC(gemm(m, 0, wt, M, E, Ea, att, Ea, W(o.proj_w), wt ? Ea : E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
                       drop_stream(step, i, 2)));                                   // r = u + dropout(proj)  :587
         if (ln)
             CHECK_RC(cmp_k_layernorm_fwd(s, a.r, m->P + o.ln2_g, m->P + o.ln2_b, a.n, a.ln2_mean, a.ln2_rstd, M, E,
@@ -654,7 +699,7 @@ static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end) {
 static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t step, bool allreduce) {
     Range range_("composer.backward");
     hipStream_t s = m->ctx->stream;
-    const int E = m->E, M = B * T, dt = m->dtype, V = m->V;
+    const int E = m->E, Ea = m->Ea, M = B * T, dt = m->dtype, V = m->V;
     const float pr = m->cfg.resid_dropout, pa = m->cfg.attn_dropout;
     const bool ln = m->cfg.use_layer_norm != 0;
     HIP_CHECK(hipMemsetAsync(m->G, 0, (size_t)m->total * 4, s));
@@ -701,19 +746,19 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
             if (!ln) CHECK_RC(drop_apply(m, m->dr, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 2)));
             dao = m->dmask;
         }
-        CHECK_RC(gemm(m, 1, 0, E, E, M, a.att, E, dao, E, m->G + o.proj_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
-                      std::max(2, wgrad_splits(M, E, E)), 0.f, 0));
+        CHECK_RC(gemm(m, 1, 0, Ea, E, M, a.att, Ea, dao, E, m->G + o.proj_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
+                      std::max(2, wgrad_splits(M, Ea, E)), 0.f, 0));
         if (!ln) CHECK_RC(colsum_any(m, dao, E, m->G + o.proj_b, M, E));
-        CHECK_RC(gemm(m, 0, 1, M, E, E, dao, E, m->w(o.proj_w), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
+        CHECK_RC(gemm(m, 0, 1, M, Ea, E, dao, E, m->w(o.proj_w), E, m->tmpE, Ea, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
                       0));                                                         // datt
         const bool det = m->slab != nullptr;     // the fused bias sums are float atomics: a separate fixed-order pass instead
-        CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, m->cfg.scale_attention,
+        CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, attn_scale(m),
                               dt, pa, m->drop_seed(), drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b));   // b_attn grad = column sums of dqkv
-        if (det) CHECK_RC(colsum_det(m, m->dqkv, 3 * E, m->G + o.attn_b, M, 3 * E));
-        CHECK_RC(gemm(m, 1, 0, E, 3 * E, M, a.u, E, m->dqkv, 3 * E, m->G + o.attn_w, 3 * E, nullptr, 0, nullptr, 0, nullptr, 0,
-                      1, std::max(2, wgrad_splits(M, E, 3 * E)), 0.f, 0));
+        if (det) CHECK_RC(colsum_det(m, m->dqkv, 3 * Ea, m->G + o.attn_b, M, 3 * Ea));
+        CHECK_RC(gemm(m, 1, 0, E, 3 * Ea, M, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w, 3 * Ea, nullptr, 0, nullptr, 0, nullptr, 0,
+                      1, std::max(2, wgrad_splits(M, E, 3 * Ea)), 0.f, 0));
         if (ln) {
-            CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
+            CHECK_RC(gemm(m, 0, 1, M, E, 3 * Ea, m->dqkv, 3 * Ea, m->w(o.attn_w), 3 * Ea, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
                           E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T
             // dx_in = LN1'(du): no skip connection around LN1; feeds layer i-1's MLP branch (or the embedding for i = 0)
             CHECK_RC(ln_bwd(m, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx, m->G + o.ln1_g,
@@ -722,7 +767,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
             dmo_ready = true;
         } else {
             dmo_ready = false;
-            CHECK_RC(gemm(m, 0, 1, M, E, 3 * E, m->dqkv, 3 * E, m->w(o.attn_w), 3 * E, m->dx, E, nullptr, 0, nullptr, 0, m->dr, E,
+            CHECK_RC(gemm(m, 0, 1, M, E, 3 * Ea, m->dqkv, 3 * Ea, m->w(o.attn_w), 3 * Ea, m->dx, E, nullptr, 0, nullptr, 0, m->dr, E,
                           0, 1, 0.f, 0));
         }
         if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end));
@@ -944,9 +989,10 @@ extern "C" int cmp_eval_step(cmp_model* m, const int32_t* x, const int32_t* y, i
 
 // presents[layer] = stack([key, value]) with key, value [B,H,T,D] (split_heads of the c_attn output; transformer.py:417-435,
 // 797-806): gathered from the qkv activation [B*T, 3E] the last forward pass saved
+// (Dk: the head size the kernels run on, D <= Dk the reference's: qkv rows are [3][H][Dk])
 template <typename T_>
-__global__ void present_gather_kernel(const T_* __restrict__ qkv, float* __restrict__ out, int B, int T, int H, int D) {
-    const int E = H * D;
+__global__ void present_gather_kernel(const T_* __restrict__ qkv, float* __restrict__ out, int B, int T, int H, int D, int Dk) {
+    const int E = H * Dk;
     const int64_t n = (int64_t)2 * B * H * T * D;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int d = (int)(i % D);
@@ -954,7 +1000,7 @@ __global__ void present_gather_kernel(const T_* __restrict__ qkv, float* __restr
         const int h = (int)((i / ((int64_t)D * T)) % H);
         const int b = (int)((i / ((int64_t)D * T * H)) % B);
         const int kv = (int)(i / ((int64_t)D * T * H * B));
-        out[i] = to_f32<T_>(qkv[((int64_t)b * T + t) * 3 * E + (1 + kv) * E + h * D + d]);
+        out[i] = to_f32<T_>(qkv[((int64_t)b * T + t) * 3 * E + (1 + kv) * E + h * Dk + d]);
     }
 }
 extern "C" int cmp_forward_generation(cmp_model* m, int64_t* gen) {
@@ -976,12 +1022,12 @@ extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* hos
     CMP_REQUIRE(B > 0 && T > 0 && !m->act.empty() && B == m->lastB && T == m->lastT,
                 "present_get: the forward pass held is [%d,%d] (batch, past + new positions), not [%d,%d]", m->lastB, m->lastT, B, T);
     HIP_CHECK(hipSetDevice(m->ctx->device));
-    const int64_t n = (int64_t)2 * B * m->H * T * m->D;
+    const int64_t n = (int64_t)2 * B * m->H * T * m->Dl;
     float* tmp = nullptr;
     HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
     const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
-    if (m->dtype == CMP_BF16) present_gather_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)m->act[layer].qkv, tmp, B, T, m->H, m->D);
-    else present_gather_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)m->act[layer].qkv, tmp, B, T, m->H, m->D);
+    if (m->dtype == CMP_BF16) present_gather_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)m->act[layer].qkv, tmp, B, T, m->H, m->Dl, m->D);
+    else present_gather_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)m->act[layer].qkv, tmp, B, T, m->H, m->Dl, m->D);
     hipError_t e = hipMemcpyAsync(host_out, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, m->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(tmp);
@@ -991,8 +1037,9 @@ extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* hos
 
 // host `past` [2, B, H, Tp, D] (fp32) -> K and V columns of rows [0, Tp) of qkv viewed as [B, Tt, 3E]; the Q columns of those
 // rows are zeroed (their attention outputs are never read)
+// (D: the head size the kernels run on, Dl <= D the reference's = the host tensor's; columns Dl..D-1 are zeroed)
 template <typename T_>
-__global__ void past_scatter_kernel(const float* __restrict__ in, T_* __restrict__ qkv, int B, int Tp, int Tt, int H, int D) {
+__global__ void past_scatter_kernel(const float* __restrict__ in, T_* __restrict__ qkv, int B, int Tp, int Tt, int H, int D, int Dl) {
     const int E = H * D;
     const int64_t n = (int64_t)2 * B * H * Tp * D, nq = (int64_t)B * Tp * E;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + nq; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1002,7 +1049,8 @@ __global__ void past_scatter_kernel(const float* __restrict__ in, T_* __restrict
             const int h = (int)((i / ((int64_t)D * Tp)) % H);
             const int b = (int)((i / ((int64_t)D * Tp * H)) % B);
             const int kv = (int)(i / ((int64_t)D * Tp * H * B));
-            qkv[((int64_t)b * Tt + t) * 3 * E + (1 + kv) * E + h * D + d] = from_f32<T_>(in[i]);
+            const float v = d < Dl ? in[((((int64_t)kv * B + b) * H + h) * Tp + t) * Dl + d] : 0.f;
+            qkv[((int64_t)b * Tt + t) * 3 * E + (1 + kv) * E + h * D + d] = from_f32<T_>(v);
         } else {
             const int64_t j = i - n;
             const int e = (int)(j % E);
@@ -1023,7 +1071,8 @@ extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int pas
     CHECK_RC(upload_xy(m, x, nullptr, B, T, past_len));
     hipStream_t s = m->ctx->stream;
     if (past_len > 0) {
-        const int64_t n = (int64_t)2 * B * m->H * past_len * m->D;
+        const int64_t n = (int64_t)2 * B * m->H * past_len * m->Dl;         // the host tensors: [2, B, H, past_len, E / H]
+        const int64_t ns = (int64_t)2 * B * m->H * past_len * m->D;        // K/V elements written (zero-padded heads included)
         float* tmp = nullptr;
         HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
         int rc = CMP_OK;
@@ -1031,9 +1080,9 @@ extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int pas
             if (!past[i]) { cmp_set_error("forward: past[%d] is null", i); rc = CMP_ERR_INVALID; break; }
             hipError_t e = hipMemcpyAsync(tmp, past[i], (size_t)n * 4, hipMemcpyHostToDevice, s);
             if (e != hipSuccess) { cmp_set_error("forward: uploading past[%d]: %s", i, hipGetErrorString(e)); rc = CMP_ERR_HIP; break; }
-            const int grid = (int)std::min<int64_t>(cdiv64(n + (int64_t)B * past_len * m->E, 256), 4096);
-            if (m->dtype == CMP_BF16) past_scatter_kernel<bf16_t><<<grid, 256, 0, s>>>(tmp, (bf16_t*)m->act[i].qkv, B, past_len, past_len + T, m->H, m->D);
-            else past_scatter_kernel<float><<<grid, 256, 0, s>>>(tmp, (float*)m->act[i].qkv, B, past_len, past_len + T, m->H, m->D);
+            const int grid = (int)std::min<int64_t>(cdiv64(ns + (int64_t)B * past_len * m->Ea, 256), 4096);
+            if (m->dtype == CMP_BF16) past_scatter_kernel<bf16_t><<<grid, 256, 0, s>>>(tmp, (bf16_t*)m->act[i].qkv, B, past_len, past_len + T, m->H, m->D, m->Dl);
+            else past_scatter_kernel<float><<<grid, 256, 0, s>>>(tmp, (float*)m->act[i].qkv, B, past_len, past_len + T, m->H, m->D, m->Dl);
             e = hipStreamSynchronize(s);          // tmp is reused by the next layer's upload
             if (e != hipSuccess) { cmp_set_error("forward: past scatter: %s", hipGetErrorString(e)); rc = CMP_ERR_HIP; }
         }
