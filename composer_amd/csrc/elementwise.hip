@@ -106,7 +106,7 @@ __global__ void embed_bwd_wpe_kernel(const T* __restrict__ dh, float* __restrict
 // LayerNorm (Keras non-fused path: biased variance, eps inside rsqrt)   transformer.py:551,563,694
 // one wave per row; a lane owns chunks (lane + 64*i) of 16 bytes.
 // =================================================================================================
-#define LN_MAXI 4
+#define LN_MAXI 8
 template <typename T, int MAXI>
 __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -633,8 +633,8 @@ int embed_bwd_run(void* stream, const int32_t* ids, const void* dh, float* dwte,
 
 static int ln_check(int E, int dtype) {
     int vn = dtype == CMP_BF16 ? 8 : 4;
-    CMP_REQUIRE(E % vn == 0 && E / vn <= 64 * LN_MAXI, "layernorm: E=%d unsupported for dtype %d (max %d)", E, dtype,
-                64 * LN_MAXI * vn);
+    CMP_REQUIRE(E % vn == 0 && E / vn <= 64 * LN_MAXI && E <= 2048, "layernorm: E=%d unsupported for dtype %d (a multiple of %d, at most 2048)",
+                E, dtype, vn);
     return CMP_OK;
 }
 
@@ -649,8 +649,8 @@ extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gam
     const int maxi = cdiv(E / vn, 64);          // 16-byte chunks per lane: 1 for E <= 512 (bf16) / 256 (fp32)
     PROF_START(6, s);
 #define LN_FWD(TT, MI) layernorm_fwd_kernel<TT, MI><<<grid, 256, 0, s>>>((const TT*)x, gamma, beta, (TT*)y, mean, rstd, rows, E, eps)
-    if (dtype == CMP_BF16) { if (maxi == 1) LN_FWD(bf16_t, 1); else if (maxi == 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4); }
-    else { if (maxi == 1) LN_FWD(float, 1); else if (maxi == 2) LN_FWD(float, 2); else LN_FWD(float, 4); }
+    if (dtype == CMP_BF16) { if (maxi == 1) LN_FWD(bf16_t, 1); else if (maxi == 2) LN_FWD(bf16_t, 2); else if (maxi <= 4) LN_FWD(bf16_t, 4); else LN_FWD(bf16_t, 8); }
+    else { if (maxi == 1) LN_FWD(float, 1); else if (maxi == 2) LN_FWD(float, 2); else if (maxi <= 4) LN_FWD(float, 4); else LN_FWD(float, 8); }
 #undef LN_FWD
     PROF_STOP(6, s, (double)rows * (2.0 * E * dtype_size(dtype) + 8.0));
     KERNEL_CHECK();
@@ -695,9 +695,13 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
     // that (and always in deterministic mode) they are folded by ln_param_reduce_kernel
     const bool direct = !deterministic && grid <= 256;
     float* dg_ = direct ? dgamma : nullptr;
-#define LN_BWD(TT, MI) layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E, (TT*)dmask, want_cs, dcfg, dg_, dbeta, colsum)
-    if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
-    else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
+    // (the cross-wave parameter-gradient reduction holds [4 waves][3][E] floats: 96 KiB at E = 2048)
+#define LN_BWD(TT, MI) do { \
+        if (smem > 65536) HIP_CHECK(hipFuncSetAttribute((const void*)layernorm_bwd_kernel<TT, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E, (TT*)dmask, want_cs, dcfg, dg_, dbeta, colsum); \
+    } while (0)
+    if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else if (maxi <= 4) LN_BWD(bf16_t, 4); else LN_BWD(bf16_t, 8); }
+    else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else if (maxi <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
 #undef LN_BWD
     KERNEL_CHECK();
     if (!direct)

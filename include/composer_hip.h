@@ -94,7 +94,7 @@ int cmp_dp_set_mask_rank(cmp_ctx* ctx, int rank);
 
 /* ---- model: replaces models.Transformer(...) construction (cli.py:123-132) --------------------- */
 /* Accepted configurations (anything else: CMP_ERR_INVALID with the reason in cmp_last_error): any vocabulary size; embedding_size
- * a multiple of 8, at most 2048 (bf16) / 1024 (fp32) (LayerNorm keeps a row in registers); embedding_size divisible by heads
+ * a multiple of 8, at most 2048 (LayerNorm keeps a row in registers); embedding_size divisible by heads
  * (transformer.py:255) with a head size of at most 128 -- 16 / 32 / 64 / 128 run natively, every other size runs zero-padded on
  * the next of those with the reference's shapes kept at this ABI (parameters, presents, past); at most 63 blocks; fp32 or bf16. */
 int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_model** out);

@@ -428,3 +428,47 @@ def test_random_small_shapes_match_the_oracle(cfg):
             worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-12))
         assert worst <= (5e-4 if dtype == "fp32" else 4e-2), (dtype, worst)
         m.close()
+
+
+def _switch_configs():
+    rng = np.random.default_rng(4242)
+    out = []
+    for scale in (False, True):
+        for use_ln in (False, True):
+            for eps in (1e-5, 1e-3):
+                H = int(rng.choice([1, 2, 4])); D = int(rng.choice([16, 24, 32, 64]))
+                W = int(rng.integers(6, 40)); T = int(rng.integers(2, W + 1))
+                out.append((390, H * D, H, int(rng.integers(1, 3)), W, T, int(rng.integers(1, 4)), scale, use_ln, eps, int(rng.integers(0, 1 << 20))))
+    # wide models (LayerNorm rows of 8 chunks per lane in fp32, the 96 KiB parameter-gradient reduction at E = 2048)
+    out += [(390, 768, 12, 1, 8, 5, 2, True, True, 1e-5, 11), (390, 1536, 12, 1, 6, 4, 2, True, True, 1e-5, 12), (390, 2048, 16, 1, 6, 3, 1, True, True, 1e-5, 13)]
+    return out
+
+
+@pytest.mark.parametrize("cfg", _switch_configs(), ids=lambda c: "E%d-H%d-L%d-W%d-T%d-B%d-scale%d-ln%d-eps%g-s%d" % c[1:])
+def test_constructor_switches_and_wide_models_match_the_oracle(cfg):
+    """scale (transformer.py:340-343), use_layer_normalization (:583-591) and layer_normalization_epsilon in all combinations, and
+    embedding sizes up to the widest accepted: loss and gradients with dropout on against the oracle, fp32 and bf16."""
+    from composer_amd import _lib
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W, T, B, scale, use_ln, eps, seed = cfg
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=seed % 1000, stddev=0.05).items()}
+    rng = np.random.default_rng(seed)
+    x, y = O.synthetic_batch(rng, V, B, T)
+    ocfg = O.Config(V, E, W, L, H, layer_normalization_epsilon=eps, scale=scale, use_layer_normalization=use_ln,
+                    attention_dropout_rate=0.1, residual_dropout_rate=0.1)
+    for dtype in ("fp32", "bf16"):
+        orc = O.OracleTransformer(ocfg, params, seed=5, emulate_bf16=(dtype == "bf16"))
+        loss, acc, G, _ = orc.loss_and_grads(x, y, training=True, step=0)
+        m = Transformer(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, layer_normalization_epsilon=eps,
+                        scale=scale, use_layer_normalization=use_ln, dtype=dtype, seed=5, max_batch=B, max_seq=W)
+        m.set_weights(params)
+        l2, _ = m.loss_and_grads(x, y)
+        assert abs(l2 - loss) <= (2e-5 if dtype == "fp32" else 2e-2) * abs(loss), (dtype, l2, loss)
+        worst = 0.0
+        for n in m.parameter_names:
+            if not use_ln and ("ln_1" in n or "ln_2" in n):
+                continue
+            gr = m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64)
+            worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-12))
+        assert worst <= (5e-4 if dtype == "fp32" else 4e-2), (dtype, worst)
+        m.close()
