@@ -472,3 +472,43 @@ def test_constructor_switches_and_wide_models_match_the_oracle(cfg):
             worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-12))
         assert worst <= (5e-4 if dtype == "fp32" else 4e-2), (dtype, worst)
         m.close()
+
+
+@pytest.mark.parametrize("cfg", [(390, 32, 2, 1, 4096, 4096, 1), (390, 64, 1, 2, 3000, 2999, 2), (17, 16, 1, 1, 16, 3, 3000)],
+                         ids=lambda c: "V%d-E%d-H%d-L%d-W%d-T%d-B%d" % c)
+def test_long_windows_and_wide_batches_match_the_oracle(cfg):
+    """Sequence lengths well past the benchmark's (4096, and a ragged 2999), and a 3000-row batch of 3 tokens: fp32 loss and
+    gradients against the oracle."""
+    from composer_amd import _lib
+    from test_gpu_model import make_model
+    V, E, H, L, W, T, B = cfg
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=3, stddev=0.1).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(5), V, B, T)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
+    loss, acc, G, _ = orc.loss_and_grads(x, y, training=False)
+    m = make_model(cfg, params, "fp32")
+    l2, a2 = m.loss_and_grads(x, y)
+    assert abs(l2 - loss) <= 2e-5 * abs(loss) and abs(a2 - acc) < 1e-6
+    worst = 0.0
+    for n in m.parameter_names:
+        gr = m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64)
+        worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-12))
+    assert worst <= 1e-3, worst
+    m.close()
+
+
+def test_decode_to_the_last_position_of_a_long_window():
+    """KV-cache decode that starts 8 positions before the end of a 2048-position window and fills it exactly (the split-key
+    attention kernel at its longest key range; one more token is an IndexError), against the oracle's past= loop."""
+    from test_gpu_model import make_model
+    V, E, H, L, W = 390, 64, 2, 2, 2048
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=9, stddev=0.3).items()}
+    prompt = np.random.default_rng(1).integers(0, V, size=W - 8).astype(np.int32)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
+    want = orc.generate_kv(prompt, 9)
+    m = make_model((V, E, H, L, W, W, 1), params, "fp32")
+    got = m.generate(prompt, 9, temperature=0.0, mode="kv")
+    assert got.tolist() == list(want)
+    with pytest.raises(IndexError):
+        m.generate(prompt, 10, temperature=0.0, mode="kv")
+    m.close()
