@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
                                                        const float* __restrict__ ln_b, float eps,
                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ y,
-                                                       float* __restrict__ u_out, int K, int N, int D) {
+                                                       float* __restrict__ u_out, int K, int N, int D, int PS) {
+    // PS: floats per attention-partial record (IN == 2): D + 2 from dec_attn_kernel, PSTRIDE(D) from dec_attn2_kernel
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [K] + 8
     float* red = xs + K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,22 +162,22 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
         const int H = K / D;
         for (int t = tid; t < H * ATT_SPLITS; t += 256) {
             const int h = t / ATT_SPLITS;
-            const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
+            const float* p = x + (size_t)h * ATT_SPLITS * PS;
             float mx = -INFINITY;
 #pragma unroll
-            for (int s = 0; s < ATT_SPLITS; s++) mx = fmaxf(mx, p[s * (D + 2) + D]);
+            for (int s = 0; s < ATT_SPLITS; s++) mx = fmaxf(mx, p[s * PS + D]);
             float den = 0.f;
 #pragma unroll
-            for (int s = 0; s < ATT_SPLITS; s++) den += expf(p[s * (D + 2) + D] - mx) * p[s * (D + 2) + D + 1];
-            cw[t] = expf(p[(t % ATT_SPLITS) * (D + 2) + D] - mx) / den;      // exp(-inf) = 0 for empty splits
+            for (int s = 0; s < ATT_SPLITS; s++) den += expf(p[s * PS + D] - mx) * p[s * PS + D + 1];
+            cw[t] = expf(p[(t % ATT_SPLITS) * PS + D] - mx) / den;      // exp(-inf) = 0 for empty splits
         }
         __syncthreads();
         for (int k = tid; k < K; k += 256) {
             const int h = k / D, dd = k % D;
-            const float* p = x + (size_t)h * ATT_SPLITS * (D + 2);
+            const float* p = x + (size_t)h * ATT_SPLITS * PS;
             float num = 0.f;
 #pragma unroll
-            for (int s = 0; s < ATT_SPLITS; s++) num += cw[h * ATT_SPLITS + s] * p[s * (D + 2) + dd];
+            for (int s = 0; s < ATT_SPLITS; s++) num += cw[h * ATT_SPLITS + s] * p[s * PS + dd];
             xs[k] = num;
         }
     } else {
@@ -195,6 +196,22 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
         if (k < K) {
             f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
             acc += xv[0] * wv[i][0] + xv[1] * wv[i][1] + xv[2] * wv[i][2] + xv[3] * wv[i][3];
+        }
+    }
+    // rows longer than one register-resident pass (K > 3072: the mlp c_proj of a model wider than 768): further passes
+    for (int k0 = 256 * GV_MAXI; k0 < K; k0 += 256 * GV_MAXI) {
+#pragma unroll
+        for (int i = 0; i < GV_MAXI; i++) {
+            const int k = k0 + (lane + 64 * i) * 4;
+            wv[i] = (k < K) ? *reinterpret_cast<const f32x4*>(wr + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < GV_MAXI; i++) {
+            const int k = k0 + (lane + 64 * i) * 4;
+            if (k < K) {
+                f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
+                acc += xv[0] * wv[i][0] + xv[1] * wv[i][1] + xv[2] * wv[i][2] + xv[3] * wv[i][3];
+            }
         }
     }
     float v = wave_sum(acc);
@@ -705,11 +722,13 @@ extern "C" int cmp_k_sample(void* stream, const float* logits, int V, float temp
 
 // -------------------------------------------------------------------------------------------------
 static int launch_gemv(hipStream_t s, int act, int in_mode, const float* x, const float* g, const float* b, float eps,
-                       const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D) {
-    CMP_REQUIRE(K % 4 == 0 && K <= 256 * GV_MAXI, "decode gemv: K=%d unsupported (max %d)", K, 256 * GV_MAXI);
+                       const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D,
+                       int PS = 0) {
+    CMP_REQUIRE(K % 4 == 0 && K <= 8192, "decode gemv: K=%d unsupported (a multiple of 4, at most 8192)", K);
+    if (!PS) PS = D + 2;
     int grid = cdiv(N, 4);
     size_t smem = (size_t)(K + 8 + (in_mode == 2 ? (K / D) * ATT_SPLITS : 0)) * 4;      // input | reduction scratch | combine weights
-#define GV(A, I) dec_gemv_kernel<A, I><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D)
+#define GV(A, I) dec_gemv_kernel<A, I><<<grid, 256, smem, s>>>(x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D, PS)
     if (act == 1) { if (in_mode == 1) GV(1, 1); else if (in_mode == 2) GV(1, 2); else GV(1, 0); }
     else { if (in_mode == 1) GV(0, 1); else if (in_mode == 2) GV(0, 2); else GV(0, 0); }
 #undef GV
@@ -719,7 +738,9 @@ static int launch_gemv(hipStream_t s, int act, int in_mode, const float* x, cons
 
 static int launch_gemv2(hipStream_t s, int act, int in_mode, const float* x, const float* g, const float* b, float eps,
                         const float* Wt, const float* bias, const float* resid, float* y, float* u_out, int K, int N, int D) {
-    CMP_REQUIRE(K % 4 == 0 && K <= 256 * GV_MAXI, "decode gemv: K=%d unsupported (max %d)", K, 256 * GV_MAXI);
+    // rows longer than the register-resident kernel holds: the workgroup-staged kernel in several passes (same partial records)
+    if (K > 256 * GV_MAXI) return launch_gemv(s, act, in_mode, x, g, b, eps, Wt, bias, resid, y, u_out, K, N, D, PSTRIDE(D));
+    CMP_REQUIRE(K % 4 == 0, "decode gemv: K=%d must be a multiple of 4", K);
     // CW = 2 columns per wave for the wide outputs of the narrow-K launches; 4, 2 or 1 waves per workgroup so that the narrow
     // outputs still give every CU a workgroup
 #ifdef DEC_NO_CW2

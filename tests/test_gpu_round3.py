@@ -512,3 +512,21 @@ def test_decode_to_the_last_position_of_a_long_window():
     with pytest.raises(IndexError):
         m.generate(prompt, 10, temperature=0.0, mode="kv")
     m.close()
+
+
+@pytest.mark.parametrize("E,H", [(1024, 8), (2048, 16), (1000, 10)])
+@pytest.mark.parametrize("v1", [False, True])
+def test_decode_of_wide_models(E, H, v1, monkeypatch):
+    """Models wider than 768: the per-token GEMV over 4E inputs (mlp c_proj) no longer fits one register-resident pass and takes
+    the staged kernel in several passes; E = 1000 with 10 heads also runs its 100-wide heads zero-padded to 128.  Greedy ids of
+    both decode modes against the oracle, with either kernel generation."""
+    from test_gpu_model import make_model
+    monkeypatch.setenv("COMPOSER_DECODE_V1", "1" if v1 else "0")
+    V, L, W = 390, 1, 12
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=E, stddev=0.05).items()}
+    prompt = np.random.default_rng(E).integers(0, V, size=5).astype(np.int32)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), params)
+    m = make_model((V, E, H, L, W, W, 1), params, "fp32")
+    assert m.generate(prompt, 6, temperature=0.0, mode="kv").tolist() == list(orc.generate_kv(prompt, 6))
+    assert m.generate(prompt, 4, temperature=0.0, mode="literal").tolist() == list(orc.generate_literal(prompt, 4))
+    m.close()
