@@ -530,3 +530,32 @@ def test_decode_of_wide_models(E, H, v1, monkeypatch):
     assert m.generate(prompt, 6, temperature=0.0, mode="kv").tolist() == list(orc.generate_kv(prompt, 6))
     assert m.generate(prompt, 4, temperature=0.0, mode="literal").tolist() == list(orc.generate_literal(prompt, 4))
     m.close()
+
+
+@pytest.mark.parametrize("fmt", ["npz", "tensorbundle"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_checkpoint_roundtrip_with_padded_heads_and_a_wide_vocabulary(tmp_path, fmt, dtype):
+    """Head size 24 (stored 32-wide) and 1384 ids: parameters and both Adam moments leave and re-enter through the reference's
+    shapes, in either checkpoint format, and the resumed model takes the bit-identical next step."""
+    from test_gpu_model import make_model
+    from composer_amd import checkpoint
+    V, E, H, L, W, T, B = 1384, 48, 2, 2, 16, 12, 3
+    cfg = (V, E, H, L, W, T, B)
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=4, stddev=0.1).items()}
+    rng = np.random.default_rng(2)
+    ds = [O.synthetic_batch(rng, V, B, T) for _ in range(5)]
+    m = make_model(cfg, params, dtype, p_attn=0.1, p_resid=0.1, seed=3)
+    m.train(ds[:4], (B, T), tmp_path / "run", epochs=2, learning_rate=1e-3, save_frequency_mode="global_step", save_frequency=2,
+            max_checkpoints=3, show_progress_bar=False, **({"checkpoint_format": fmt} if fmt != "npz" else {}))
+    assert m.iterations == 4
+    w_ref = m.get_weights()
+    assert w_ref["decoder_blocks/0/attn/c_attn/weight"].shape == (E, 3 * E) and w_ref["decoder_blocks/1/attn/c_proj/weight"].shape == (E, E)
+    nxt = m.train_step(*ds[4], 1e-3)
+    m2 = make_model(cfg, params, dtype, p_attn=0.1, p_resid=0.1, seed=3)
+    m2.load_state_dict(checkpoint.load(str(tmp_path / "run" / "ckpt-2"))[0])
+    for n in w_ref:
+        assert np.array_equal(m2.get_parameter(n), w_ref[n]), n
+    assert m2.iterations == 4
+    nxt2 = m2.train_step(*ds[4], 1e-3)
+    assert nxt[0] == nxt2[0] or abs(nxt[0] - nxt2[0]) < 1e-6
+    m.close(); m2.close()
