@@ -153,3 +153,49 @@ def test_train_from_tfrecord_matches_directory_and_logs_events(tmp_path):
     for n in model.parameter_names:
         assert np.array_equal(model.get_parameter(n), sd["model/" + n]), n
     model.close()
+
+
+def test_cli_with_a_non_default_event_vocabulary_and_head_size(tmp_path):
+    """A config.yml the reference accepts and the benchmark configurations never exercise: dataset settings (5, 1000, 64) give a
+    1322-word vocabulary (the wide loss kernel), embedding 72 over 3 heads a head size of 24 (zero-padded to 32): train, evaluate
+    and both generate modes through the CLI against the oracle on the same batches."""
+    from composer_amd import cli, config, dataset as D
+    root = tmp_path / "data"
+    (root / "train").mkdir(parents=True); (root / "test").mkdir()
+    st = dict(time_step_increment=5, max_time_steps=1000, velocity_bins=64)
+    V = D.vocab_size(5, 1000, 64)
+    assert V == 1322
+    D.write_synthetic_data_file(root / "train" / "a.data", 33 * 8 + 5, seed=21, **st)     # 8 windows of 33
+    D.write_synthetic_data_file(root / "test" / "b.data", 33 * 2 + 1, seed=22, **st)
+    cfg = yaml.safe_load(open(cli.get_default_config()))
+    cfg["dataset"].update(st)
+    cfg["transformer"]["model"].update(window_size=32, embedding_size=72, attention_head_count=3, decoder_layers_count=2,
+                                       attention_dropout_rate=0.0, residual_dropout_rate=0.0, initializer_stddev=0.1)
+    cfg["transformer"]["train"]["batch_size"] = 2
+    cfg["transformer"]["runtime"] = {"dtype": "fp32", "seed": 5}
+    cfg_path = tmp_path / "cfg.yml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    r = CliRunner()
+    res = r.invoke(cli.cli, ["train", "transformer", str(root), "--logdir", str(tmp_path / "logs"), "-c", str(cfg_path), "-e", "2",
+                             "--save-freq", "2", "--no-show-progress-bar"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    run = [p for p in (tmp_path / "logs").iterdir()][0]
+    scal = [eval(l.replace("true", "True")) for l in (run / "train" / "scalars.jsonl").read_text().strip().split("\n")]
+    hip_loss = [s["value"] for s in scal if s["tag"] == "loss"]
+    assert len(hip_loss) == 4
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, 72, 32, 2, seed=5, stddev=0.1).items()}
+    orc = O.OracleTransformer(O.Config(V, 72, 32, 2, 3), params)
+    files = D.get_processed_files(root / "train")
+    np.random.default_rng(5).shuffle(files)
+    ref = [orc.train_step(x, y, 1e-3, training=False)[0] for x, y in D.load_dataset(files, 2, 32, shuffle=True, seed=5)]
+    assert np.allclose(hip_loss, ref, rtol=2e-4), (hip_loss, ref)
+    res = r.invoke(cli.cli, ["evaluate", "transformer", str(root), str(run)], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    prompt = D.read_data_file(root / "test" / "b.data")[0][:6].astype(int).tolist()
+    for mode, fn in (("kv-cache", orc.generate_kv), ("reference-literal", orc.generate_literal)):
+        res = r.invoke(cli.cli, ["generate", "transformer", str(run), str(tmp_path / "out.data"), "--prompt-data", str(root / "test" / "b.data"),
+                                 "--prompt-length", "6", "--length", "12", "--temperature", "0", "--decode-mode", mode], catch_exceptions=False)
+        assert res.exit_code == 0, res.output
+        ids = [int(t) for t in res.output.strip().split("\n")[-1].split(",")]
+        want = fn(prompt, 12)
+        assert len(ids) == 12 and sum(a == b for a, b in zip(ids, want)) >= 11, (mode, ids, want)
