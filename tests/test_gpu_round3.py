@@ -38,14 +38,15 @@ def chi_square_p(counts, probs, min_expected=8.0):
     return float(stats.chi2.sf(stat, dof)), dof
 
 
-@pytest.mark.parametrize("temperature", [0.7, 1.0, 1.6])
-def test_sampler_distribution_matches_the_oracle_softmax(temperature):
-    """200 000 draws of the decode chain's sampler (cmp_k_sample = the code dec_sample2_kernel runs) from ONE row of V=390
-    logits: a few dominant columns, a broad middle, columns with probability ~1e-9 (never drawn) and exact ties."""
+@pytest.mark.parametrize("temperature,V", [(0.7, 390), (1.0, 390), (1.6, 390), (1.0, 1384)])
+def test_sampler_distribution_matches_the_oracle_softmax(temperature, V):
+    """200 000 draws of the decode chain's sampler (cmp_k_sample = the code dec_sample2_kernel runs) from ONE row of V logits
+    (the default vocabulary's 390, and 1384 -- more than five columns per thread of the sampling workgroup): a few dominant
+    columns, a broad middle, columns with probability ~1e-9 (never drawn) and exact ties."""
     import torch
     from composer_amd import _lib
     lib = _lib.load(); _lib.require_gpu()
-    V, n = 390, 200_000
+    n = 200_000
     rng = np.random.default_rng(5)
     z = rng.standard_normal(V).astype(np.float32) * 1.5
     z[[3, 77, 200]] += 4.0                      # dominant
