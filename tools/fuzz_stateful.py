@@ -6,7 +6,8 @@ iteration count) before every operation -- so every comparison is a one-operatio
 product (decode state and its transposed weights, presents of an older pass, workspaces sized by an earlier shape, the pipelined
 loop's staging slots, dropout streams keyed on the iteration) shows up:
   train_step | three pipelined train_step_async | loss_and_grads | evaluate | forward | forward with past (chain) |
-  training=True forward | greedy generate (kv / literal) | state_dict -> perturb -> load_state_dict | set one weight."""
+  training=True forward | greedy generate (kv / literal) | state_dict -> perturb -> load_state_dict | set one weight.
+FUZZ_DP=1: every model joins a 1-rank RCCL communicator first (the data-parallel code path of the train step)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,6 +47,8 @@ def run_model(rng, nops, log):
     orc = O.OracleTransformer(ocfg, params, seed=11)
     m = Transformer(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p, dtype="fp32", seed=11, max_batch=maxB, max_seq=W)
     m.set_weights(params)
+    if os.environ.get("FUZZ_DP"):           # the product's data-parallel path with a 1-rank communicator (buckets, side stream, RCCL, 1/N)
+        m.init_data_parallel(0, 1, Transformer.new_unique_id())
     lr = 1e-3
     try:
         for _ in range(nops):
