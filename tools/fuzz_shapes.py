@@ -19,10 +19,11 @@ def draw(rng):
         Dl = int(rng.integers(1, 33)) * 4 if rng.random() < 0.7 else int(rng.choice([16, 32, 64, 128]))
         H = int(rng.choice([1, 2, 3, 4, 5, 6, 8]))
         E = Dl * H
-        if E % 8 or E > 512 or Dl > 128:
+        wide = os.environ.get("FUZZ_WIDE")               # FUZZ_WIDE=1: widths up to 1024 and windows up to 400
+        if E % 8 or E > (1024 if wide else 512) or Dl > 128:
             continue
         L = int(rng.integers(1, 4))
-        W = int(rng.integers(1, 90))
+        W = int(rng.integers(1, 400 if wide and rng.random() < 0.3 else 90))
         T = int(rng.integers(1, W + 1))
         B = int(rng.integers(1, 7))
         V = int(rng.choice([2, 3, 17, 390, 513, 1000, 2500]))
@@ -56,7 +57,9 @@ def check(c):
             if not c["use_ln"] and ("ln_1" in n or "ln_2" in n):
                 continue
             gr = m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64)
-            worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-12))
+            # relative to the tensor's largest element, with a floor: a gradient that cancels to ~1e-7 (ln_f/beta with a two-word
+            # vocabulary) carries fp32 rounding residue of the same size
+            worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-5))
         assert worst <= (1e-3 if not bf else 5e-2), ("grad", worst)
         lg, pres = m(x)
         want, opast, _ = orc.forward(x)
