@@ -790,7 +790,11 @@ static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
     const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->Dl) : 1.0f;
     for (int i = 0; i < L; i++) {
         const LayerOff& o = m->lo[i];
+#ifdef DEC_ALIAS_L0     // timing experiment only (wrong results): every block reads block 0's weights, which then stay in L2
+        const DecLayerW w = [&] { DecLayerW t = d->lw[0]; t.kc = d->lw[i].kc; t.vc = d->lw[i].vc; return t; }();
+#else
         const DecLayerW& w = d->lw[i];
+#endif
         if (!(skip & 1)) CHECK_RC(launch_gemv2(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
                               d->qkv, d->u, E, 3 * Ea, m->D));
         if (!(skip & 2)) CHECK_RC(launch_attn2(s, m, d, w, scale));
