@@ -44,8 +44,10 @@ def run_model(rng, nops, log):
     log.append(("model", cfg))
     params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=int(rng.integers(0, 1000)), stddev=0.05).items()}
     ocfg = O.Config(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p)
-    orc = O.OracleTransformer(ocfg, params, seed=11)
-    m = Transformer(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p, dtype="fp32", seed=11, max_batch=maxB, max_seq=W)
+    bf = os.environ.get("FUZZ_DTYPE", "fp32") == "bf16"      # bf16: against the oracle that rounds where the bf16 kernels round
+    orc = O.OracleTransformer(ocfg, params, seed=11, emulate_bf16=bf)
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p, dtype="bf16" if bf else "fp32", seed=11, max_batch=maxB, max_seq=W)
+    k = 700.0 if bf else 1.0                                 # tolerance scale
     m.set_weights(params)
     if os.environ.get("FUZZ_DP"):           # the product's data-parallel path with a 1-rank communicator (buckets, side stream, RCCL, 1/N)
         m.init_data_parallel(0, 1, Transformer.new_unique_id())
@@ -60,8 +62,10 @@ def run_model(rng, nops, log):
             if op == "train":
                 lo, ao = orc.train_step(x, y, lr, training=p > 0)
                 lm, am = m.train_step(x, y, lr)
-                close(lm, lo, 3e-5, "train loss"); assert abs(am - ao) < 1e-6
-                for n in m.parameter_names:
+                close(lm, lo, 3e-5 * k, "train loss"); assert bf or abs(am - ao) < 1e-6
+                # (bf16: Adam's first steps move every element by ~lr * sign(g), so an element whose gradient is within the bf16 error
+                # of zero lands 2 * lr away -- the parameters are compared in fp32 only)
+                for n in ([] if bf else m.parameter_names):
                     close(m.get_parameter(n), orc.p[n], 3e-5, "param " + n)
                 assert m.iterations == orc.iterations
             elif op == "async":
@@ -70,24 +74,24 @@ def run_model(rng, nops, log):
                 want = [orc.train_step(bx, by, lr, training=p > 0) for bx, by in batches]
                 for tk, (lo, ao) in zip(tickets, want):
                     lm, am = m.step_metrics(tk)
-                    close(lm, lo, 1e-4, "async loss")
-                for n in m.parameter_names:
+                    close(lm, lo, 1e-4 * k / 3, "async loss")
+                for n in ([] if bf else m.parameter_names):
                     close(m.get_parameter(n), orc.p[n], 1e-4, "async param " + n)
             elif op == "grads":
                 lo, ao, G, _ = orc.loss_and_grads(x, y, training=p > 0, step=orc.iterations)
                 lm, am = m.loss_and_grads(x, y)
-                close(lm, lo, 3e-5, "grads loss")
-                worst = max(np.abs(m.get_parameter(n, _lib.KIND_GRAD) - G[n]).max() / (np.abs(G[n]).max() + 1e-12) for n in m.parameter_names)
-                assert worst < 1e-3, ("grad", worst)
+                close(lm, lo, 3e-5 * k, "grads loss")
+                worst = max(np.abs(m.get_parameter(n, _lib.KIND_GRAD) - G[n]).max() / (np.abs(G[n]).max() + 1e-5) for n in m.parameter_names)
+                assert worst < (5e-2 if bf else 1e-3), ("grad", worst)
             elif op == "eval":
                 lm, am = m.evaluate([(x, y)])
                 lo, ao = orc.loss_acc(orc.forward(x)[0], y)
-                close(lm, lo, 3e-5, "eval loss"); assert abs(am - ao) < 1e-6
+                close(lm, lo, 3e-5 * k, "eval loss"); assert bf or abs(am - ao) < 1e-6
             elif op == "fwd":
                 lg, pres = m(x)
                 want, opast, _ = orc.forward(x)
-                close(lg, want, 2e-4, "logits")
-                close(np.array(pres[L - 1]), opast[L - 1], 3e-5, "presents")
+                close(lg, want, 2e-4 * k / 4, "logits")
+                close(np.array(pres[L - 1]), opast[L - 1], 3e-5 * k, "presents")
             elif op == "past":
                 if T == W:
                     continue
@@ -99,11 +103,11 @@ def run_model(rng, nops, log):
                     cur = np.concatenate([cur, nxt], axis=1)
                     lg, pres = m(cur, past=pres)
                     want, opast, _ = orc.forward(nxt, past=opast)
-                    close(lg, want, 2e-4, "past logits")
+                    close(lg, want, 2e-4 * k / 4, "past logits")
             elif op == "fwd_train":
                 lg, _ = m(x, training=True)
                 want, _, _ = orc.forward(x, training=p > 0, step=orc.iterations)
-                close(lg, want, 2e-4, "training logits")
+                close(lg, want, 2e-4 * k / 4, "training logits")
             elif op in ("gen_kv", "gen_lit"):
                 Pn = int(rng.integers(1, W + 1)); prompt = rng.integers(0, V, size=Pn).astype(np.int32)
                 n = int(rng.integers(1, 6))
@@ -116,7 +120,7 @@ def run_model(rng, nops, log):
                     got = m.generate(prompt, n, temperature=0.0, mode="literal").tolist(); want = list(orc.generate_literal(prompt, n))
                 z = orc.forward(prompt[None])[0][0, -1]
                 top = np.sort(z)[-2:]
-                if V > 1 and top[1] - top[0] > 1e-3:
+                if V > 1 and top[1] - top[0] > (1e-3 if not bf else 0.2):      # decode runs on the fp32 master weights in either mode
                     assert got[0] == want[0], (op, got, want)
             elif op == "reload":
                 sd = m.state_dict()
