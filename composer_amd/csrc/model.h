@@ -103,6 +103,7 @@ struct cmp_model {
     std::vector<void*> xs;     // L+1 residual-stream tensors
     std::vector<LayerAct> act;
     void *hf = nullptr, *dlogits = nullptr;
+    float* logits_pack = nullptr;      // [tokens, V] contiguous copy of the logits for cmp_forward's host transfer (allocated on first use)
     float *logits = nullptr, *lnf_mean = nullptr, *lnf_rstd = nullptr, *row_loss = nullptr, *delta = nullptr;
     int32_t *row_correct = nullptr, *x_dev = nullptr, *y_dev = nullptr;
     void *dx = nullptr, *dr = nullptr, *tmpE = nullptr, *dmask = nullptr, *dfc = nullptr, *dqkv = nullptr;

@@ -1061,6 +1061,11 @@ __global__ void past_scatter_kernel(const float* __restrict__ in, T_* __restrict
     }
 }
 
+__global__ void logits_pack_kernel(const float* __restrict__ z, float* __restrict__ out, int64_t n, int V, int ldz) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = z[(i / V) * ldz + (i % V)];
+}
+
 extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                            float* logits_out) {
     CMP_REQUIRE(m && x && logits_out, "forward: null argument");
@@ -1090,8 +1095,17 @@ extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int pas
         CHECK_RC(rc);
     }
     CHECK_RC(model_forward(m, m->x_dev, B, T, training != 0, m->iterations, past_len));
-    HIP_CHECK(hipMemcpy2DAsync(logits_out, (size_t)m->V * 4, m->logits, (size_t)m->ldz * 4, (size_t)m->V * 4, (size_t)B * T,
-                               hipMemcpyDeviceToHost, s));
+    // [tokens, ldz] -> [tokens, V] on the device, then ONE contiguous copy: hipMemcpy2DAsync to pageable host memory left 2 MiB of
+    // device memory behind per context (tools/leak_probe.py)
+    if (m->ldz == m->V) {
+        HIP_CHECK(hipMemcpyAsync(logits_out, m->logits, (size_t)B * T * m->V * 4, hipMemcpyDeviceToHost, s));
+    } else {
+        if (!m->logits_pack) CHECK_RC(dev_alloc(m, &m->logits_pack, (size_t)m->capB * m->capT * m->V * 4));
+        const int64_t n = (int64_t)B * T * m->V;
+        logits_pack_kernel<<<(int)std::min<int64_t>(cdiv64(n, 256), 4096), 256, 0, s>>>(m->logits, m->logits_pack, n, m->V, m->ldz);
+        KERNEL_CHECK();
+        HIP_CHECK(hipMemcpyAsync(logits_out, m->logits_pack, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     return CMP_OK;
 }
