@@ -54,7 +54,7 @@ def run_model(rng, nops, log):
     lr = 1e-3
     try:
         for _ in range(nops):
-            op = str(rng.choice(["train", "train", "async", "grads", "eval", "fwd", "past", "fwd_train", "gen_kv", "gen_lit", "reload", "setw"]))
+            op = str(rng.choice(["train", "train", "async", "grads", "eval", "fwd", "past", "fwd_train", "gen_kv", "gen_lit", "reload", "setw", "bad"]))
             B = int(rng.integers(1, maxB + 1)); T = int(rng.integers(1, W + 1))
             x, y = O.synthetic_batch(rng, V, B, T)
             log.append((op, B, T))
@@ -130,6 +130,28 @@ def run_model(rng, nops, log):
                 for n in m.parameter_names:
                     assert np.array_equal(m.get_parameter(n), sd["model/" + n]), n
                 assert m.iterations == int(sd["optimizer/iter"])
+            elif op == "bad":
+                # a refused call must leave the model exactly as it was (the operations after it are checked as usual)
+                kind = int(rng.integers(0, 6))
+                before = m.iterations
+                try:
+                    if kind == 0:
+                        bx = x.copy(); bx[0, 0] = V; m.train_step(bx, y, lr)
+                    elif kind == 1:
+                        by = y.copy(); by[-1, -1] = -1; m.train_step_async(x, by, lr)
+                    elif kind == 2:
+                        m(np.zeros((1, W + 1), np.int32))
+                    elif kind == 3:
+                        m.generate(np.zeros(W, np.int32), 2, temperature=0.0, mode="kv")
+                    elif kind == 4:
+                        m(x, past=[np.zeros((2, B, H, 3, E // H + 1), np.float32)] * L)
+                    else:
+                        m.evaluate([(np.full((1, 2), V + 5, np.int32), np.zeros((1, 2), np.int32))])
+                    raise AssertionError("bad call %d was accepted" % kind)
+                except (ValueError, IndexError, RuntimeError) as e:
+                    if isinstance(e, AssertionError):
+                        raise
+                assert m.iterations == before
             elif op == "setw":
                 n = str(rng.choice(m.parameter_names))
                 w = m.get_parameter(n)
