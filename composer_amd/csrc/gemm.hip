@@ -1704,7 +1704,7 @@ static int sched_next(hipStream_t s, Epilogue& ep, bool dp) {
     SchedWs& w = tab[std::make_pair(dev, s)];
     if (!w.dev) {
         HIP_CHECK(hipMalloc((void**)&w.dev, 2 * SCHED_SET_WORDS * 4));
-        HIP_CHECK(hipMemset(w.dev, 0, 2 * SCHED_SET_WORDS * 4));
+        HIP_CHECK(hipMemsetAsync(w.dev, 0, 2 * SCHED_SET_WORDS * 4, s));      // on the launch's own stream: no legacy-stream call (another thread may be capturing)
     }
     ep.sched = w.dev + w.parity * SCHED_SET_WORDS;
     ep.sched_clear = w.dev + (w.parity ^ 1) * SCHED_SET_WORDS;

@@ -63,7 +63,7 @@ extern "C" int cmp_prof_begin(int cls) {
 }
 extern "C" int cmp_prof_end(double* total_ms, int64_t* launches, double* work) {
     g_prof_cls = -1;
-    HIP_CHECK(hipDeviceSynchronize());
+    if (g_prof_used >= 2) HIP_CHECK(hipEventSynchronize(g_prof_ev[g_prof_used - 1]));       // the last recorded stop event (same stream order)
     double t = 0.0;
     for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
         float ms = 0.f;
@@ -132,7 +132,10 @@ extern "C" int cmp_ctx_create(int device, cmp_ctx** out) {
 extern "C" int cmp_ctx_destroy(cmp_ctx* c) {
     if (!c) return CMP_OK;
     hipSetDevice(c->device);
-    hipDeviceSynchronize();
+    // this context's own streams only: a device-wide (or legacy-stream) wait is an error while ANOTHER thread's context captures a graph
+    hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->comm_stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->comm) ncclCommDestroy(c->comm);
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->comm_stream);
@@ -202,10 +205,10 @@ extern "C" int cmp_dp_allreduce_test(cmp_ctx* c, float* host_inout, int n) {
     CMP_REQUIRE(c && c->comm, "dp_allreduce_test: communicator not initialised");
     float* d = nullptr;
     HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
-    HIP_CHECK(hipMemcpy(d, host_inout, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpyAsync(d, host_inout, (size_t)n * 4, hipMemcpyHostToDevice, c->comm_stream));
     NCCL_CHECK(ncclAllReduce(d, d, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
+    HIP_CHECK(hipMemcpyAsync(host_inout, d, (size_t)n * 4, hipMemcpyDeviceToHost, c->comm_stream));
     HIP_CHECK(hipStreamSynchronize(c->comm_stream));
-    HIP_CHECK(hipMemcpy(host_inout, d, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipFree(d));
     return CMP_OK;
 }
@@ -298,7 +301,8 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
             wd.push_back({o.pr_w, 4 * m->E, m->E});
         }
         CHECK_RC(dev_alloc(m, &m->wdesc, wd.size() * sizeof(WDesc)));
-        HIP_CHECK(hipMemcpy(m->wdesc, wd.data(), wd.size() * sizeof(WDesc), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(m->wdesc, wd.data(), wd.size() * sizeof(WDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));      // wd is a local
     }
     CHECK_RC(dev_alloc(m, &m->metrics, sizeof(Metrics)));
     CHECK_RC(dev_alloc(m, &m->dp_metrics, 16));
@@ -316,7 +320,9 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
 extern "C" int cmp_model_destroy(cmp_model* m) {
     if (!m) return CMP_OK;
     hipSetDevice(m->ctx->device);
-    hipDeviceSynchronize();
+    hipStreamSynchronize(m->ctx->stream);
+    hipStreamSynchronize(m->ctx->comm_stream);
+    if (m->ctx->copy_stream) hipStreamSynchronize(m->ctx->copy_stream);
     if (m->dec) decode_state_free(m->dec);
     for (void* p : m->allocs) hipFree(p);
     if (m->metrics_host) hipHostFree(m->metrics_host);
@@ -393,11 +399,14 @@ extern "C" int cmp_param_get(cmp_model* m, const char* name, int kind, float* ho
     HIP_CHECK(hipStreamSynchronize(m->ctx->comm_stream));
     if (p.pad) {
         std::vector<float> st((size_t)p.store);
-        HIP_CHECK(hipMemcpy(st.data(), b + p.offset, (size_t)p.store * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpyAsync(st.data(), b + p.offset, (size_t)p.store * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
         pad_copy(m, p, st.data(), host, false);
         return CMP_OK;
     }
-    HIP_CHECK(hipMemcpy(host, b + p.offset, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    // (stream-ordered copies on the model's own stream, never the legacy stream: another thread's model may be capturing its decode graph)
+    HIP_CHECK(hipMemcpyAsync(host, b + p.offset, (size_t)numel * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     return CMP_OK;
 }
 extern "C" int cmp_param_set(cmp_model* m, const char* name, int kind, const float* host, int64_t numel) {
@@ -412,9 +421,11 @@ extern "C" int cmp_param_set(cmp_model* m, const char* name, int kind, const flo
     if (p.pad) {
         std::vector<float> st((size_t)p.store, 0.f);
         pad_copy(m, p, st.data(), const_cast<float*>(host), true);
-        HIP_CHECK(hipMemcpy(b + p.offset, st.data(), (size_t)p.store * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(b + p.offset, st.data(), (size_t)p.store * 4, hipMemcpyHostToDevice, m->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     } else {
-        HIP_CHECK(hipMemcpy(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice, m->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     }
     if (kind == 0) m->param_version += 1;
     if (kind == 0 && m->S) {
