@@ -21,18 +21,24 @@ def work(tag, steps, out):
 def work_(tag, steps, out):
     cfgs = {"a": (390, 128, 4, 2, 64, 4, "bf16"), "b": (1000, 96, 2, 3, 40, 3, "fp32")}
     V, E, H, L, W, B, dt = cfgs[tag]
-    m = Transformer(V, E, W, L, H, dtype=dt, seed=5, max_batch=B, max_seq=W, attention_dropout_rate=0.1, residual_dropout_rate=0.1)
-    m.initialize_parameters(3)
-    rng = np.random.default_rng(7)
     res = []
-    for i in range(steps):
-        x, y = O.synthetic_batch(rng, V, B, W)
-        res.append(m.train_step(x, y, 1e-3)[0])
-        if i % 5 == 0:
-            res.append(float(m.evaluate([(x, y)])[0]))
-            res.extend(m.generate(x[0, :6], 5, temperature=0.0, mode="kv").tolist())
-            t = m.train_step_async(x, y, 1e-3); res.append(m.step_metrics(t)[0])
-    m.close()
+    for gen in range(int(os.environ.get("THREAD_MODELS", "1"))):       # successive models: each one's first generate captures its graph
+        m = Transformer(V, E, W, L, H, dtype=dt, seed=5 + gen, max_batch=B, max_seq=W, attention_dropout_rate=0.1, residual_dropout_rate=0.1)
+        m.initialize_parameters(3 + gen)
+        rng = np.random.default_rng(7 + gen)
+        for i in range(steps):
+            x, y = O.synthetic_batch(rng, V, B, W)
+            res.append(m.train_step(x, y, 1e-3)[0])
+            if i % 5 == 0:
+                res.append(float(m.evaluate([(x, y)])[0]))
+                res.extend(m.generate(x[0, :6], 5, temperature=0.0, mode="kv").tolist())
+                t = m.train_step_async(x, y, 1e-3); res.append(m.step_metrics(t)[0])
+            if i % 7 == 0:                                             # forward, presents (temporary device buffers), past, weight I/O
+                lg, pres = m(x[:, :W - 1]); p0 = np.array(pres[0])
+                l2, _ = m(x, past=pres)
+                res.append(float(np.abs(lg).sum())); res.append(float(np.abs(p0).sum())); res.append(float(np.abs(l2).sum()))
+                n0 = m.parameter_names[3]; m.set_parameter(n0, m.get_parameter(n0))
+        m.close()
     out[tag] = res
 
 
