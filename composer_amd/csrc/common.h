@@ -29,6 +29,7 @@ void cmp_set_error(const char* fmt, ...);
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) {                                                                \
             cmp_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            (void)hipGetLastError();   /* reported: do not leave it for the next KERNEL_CHECK of this thread to find */ \
             return CMP_ERR_HIP;                                                                \
         }                                                                                      \
     } while (0)

@@ -236,6 +236,9 @@ static int64_t add_param(cmp_model* m, const std::string& name, int rank, int64_
 }
 
 
+static int model_create_fill(cmp_model* m, cmp_ctx* ctx, const cmp_model_cfg* cfg, int V, int E, int W, int L, int H, int D, int Dl);
+extern "C" int cmp_model_destroy(cmp_model* m);
+
 extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_model** out) {
     CMP_REQUIRE(ctx && cfg && out, "model_create: null argument");
     const int V = cfg->vocab_size, E = cfg->embedding_size, W = cfg->window_size, L = cfg->layers, H = cfg->heads;
@@ -250,6 +253,14 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     HIP_CHECK(hipSetDevice(ctx->device));
     cmp_model* m = new cmp_model();
     m->ctx = ctx;
+    // a failure part-way (an allocation, an event) must not leave the buffers allocated so far behind
+    const int rc = model_create_fill(m, ctx, cfg, V, E, W, L, H, D, Dl);
+    if (rc != CMP_OK) { cmp_model_destroy(m); return rc; }
+    *out = m;
+    return CMP_OK;
+}
+
+static int model_create_fill(cmp_model* m, cmp_ctx* ctx, const cmp_model_cfg* cfg, int V, int E, int W, int L, int H, int D, int Dl) {
     m->cfg = *cfg;
     m->V = V; m->E = E; m->W = W; m->L = L; m->H = H; m->D = D; m->Dl = Dl; m->Ea = H * D;
     m->ldz = (V + 63) / 64 * 64;
@@ -313,7 +324,6 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     HIP_CHECK(hipEventCreateWithFlags(&m->comm_done, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&m->metrics_ev, hipEventDisableTiming));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    *out = m;
     return CMP_OK;
 }
 
@@ -336,6 +346,7 @@ extern "C" int cmp_model_destroy(cmp_model* m) {
     if (m->comm_done) hipEventDestroy(m->comm_done);
     if (m->metrics_ev) hipEventDestroy(m->metrics_ev);
     delete m;
+    (void)hipGetLastError();        // whatever a teardown call reported must not surface in this thread's next launch check
     return CMP_OK;
 }
 

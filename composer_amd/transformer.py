@@ -94,7 +94,13 @@ class Transformer:
                             float(attention_dropout_rate), float(residual_dropout_rate), self.dtype,
                             int(max_batch), int(max_seq or window_size), self.seed)
         h = C.c_void_p()
-        _lib.check(self._lib.cmp_model_create(self._ctx, C.byref(cfg), C.byref(h)), 'cmp_model_create')
+        rc = self._lib.cmp_model_create(self._ctx, C.byref(cfg), C.byref(h))
+        if rc != 0:
+            msg = _lib.last_error()
+            if self._own_ctx:                       # a refused configuration must not leave its context (three streams) behind
+                self._lib.cmp_ctx_destroy(self._ctx)
+            self._ctx = None
+            raise _lib.HipLibraryError("cmp_model_create failed (status %d): %s" % (rc, msg))
         self._h = h
         self._specs = self._param_specs()
         self._learning_rate = 1e-3
@@ -108,6 +114,9 @@ class Transformer:
             self._h = None
             if self._own_ctx and self._ctx:
                 self._lib.cmp_ctx_destroy(self._ctx)
+            self._ctx = None
+        elif getattr(self, '_ctx', None) and getattr(self, '_own_ctx', False):     # construction stopped after the context
+            self._lib.cmp_ctx_destroy(self._ctx)
             self._ctx = None
 
     def __del__(self):

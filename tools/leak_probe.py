@@ -11,6 +11,12 @@ from oracle import transformer_oracle as O
 WHAT = os.environ.get("LEAK_WHAT", "train,async,eval,fwd,gen,dp").split(",")      # which uses to include (to localise a leak)
 
 def one(i):
+    if "oom" in WHAT:                       # a model whose parameter buffers cannot be allocated: refused, nothing left behind
+        try:
+            Transformer(390, 2048, 12_000_000, 1, 16, dtype="fp32", seed=i, max_batch=1, max_seq=8)
+            raise SystemExit("the 390 GB model was created?")
+        except Exception as e:
+            assert "out of memory" in str(e).lower() or "hipMalloc" in str(e), str(e)[:200]
     V, E, H, L, W, B = 390, 128, 4, 2, 64, 4
     m = Transformer(V, E, W, L, H, dtype="bf16" if i % 2 else "fp32", seed=i, max_batch=B, max_seq=W)
     m.initialize_parameters(i)
