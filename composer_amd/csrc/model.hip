@@ -460,7 +460,21 @@ extern "C" int cmp_adam_iter_set(cmp_model* m, int64_t it) {
 // -------------------------------------------------------------------------------------------------
 // workspace
 // -------------------------------------------------------------------------------------------------
+static int ensure_workspace_fill(cmp_model* m, int B, int T);
 int ensure_workspace(cmp_model* m, int B, int T) {
+    const size_t mark = m->allocs.size();
+    const int rc = ensure_workspace_fill(m, B, T);
+    if (rc != CMP_OK && m->allocs.size() > mark) {
+        // an allocation failed part-way: give back what this attempt took (a retry would otherwise allocate it all again)
+        for (size_t i = mark; i < m->allocs.size(); i++) (void)hipFree(m->allocs[i]);
+        m->allocs.resize(mark);
+        m->xs.clear(); m->act.clear();
+        m->capB = 0; m->capT = 0;
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+static int ensure_workspace_fill(cmp_model* m, int B, int T) {
     CMP_REQUIRE(B > 0 && T > 0, "batch and sequence must be positive (B=%d T=%d)", B, T);
     CMP_REQUIRE(T <= m->W, "sequence length %d exceeds window_size %d (wpe rows, transformer.py:675-679)", T, m->W);
     if (m->capB * m->capT >= B * T && m->capB > 0) return CMP_OK;

@@ -17,6 +17,17 @@ def one(i):
             raise SystemExit("the 390 GB model was created?")
         except Exception as e:
             assert "out of memory" in str(e).lower() or "hipMalloc" in str(e), str(e)[:200]
+    if "wsoom" in WHAT:                     # parameters fit, the workspace for max_batch * max_seq tokens does not
+        big = Transformer(390, 512, 1024, 6, 8, dtype="bf16", seed=i, max_batch=8192, max_seq=1024)
+        big.initialize_parameters(0)
+        xb = np.zeros((1, 16), np.int32)
+        for _ in range(2):
+            try:
+                big.train_step(xb, xb, 1e-3)
+                raise SystemExit("an 8192 x 1024-token workspace was allocated?")
+            except Exception as e:
+                assert "out of memory" in str(e).lower(), str(e)[:200]
+        big.close()
     V, E, H, L, W, B = 390, 128, 4, 2, 64, 4
     m = Transformer(V, E, W, L, H, dtype="bf16" if i % 2 else "fp32", seed=i, max_batch=B, max_seq=W)
     m.initialize_parameters(i)
