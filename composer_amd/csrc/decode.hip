@@ -856,6 +856,11 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     const bool v1 = [] { const char* e = getenv("COMPOSER_DECODE_V1"); return e && e[0] == '1'; }();
     const bool graph_on = [] { const char* e = getenv("COMPOSER_NO_GRAPH"); return !(e && e[0] == '1'); }();
     DecodeState* d = m->dec;
+    if (d && !d->built) {                       // an earlier call failed part-way (an allocation, the capture): start over
+        HIP_CHECK(hipStreamSynchronize(s));
+        decode_state_free(d);
+        m->dec = d = nullptr;
+    }
     if (d && d->built && (d->graph_is_v1 != v1 || d->graph_on != graph_on)) {
         HIP_CHECK(hipStreamSynchronize(s));
         decode_state_free(d);
