@@ -124,7 +124,7 @@ def cpu_baseline(cf, seconds_budget=24.0):
         import torch
         from oracle.torch_restatement import TorchTrainer
         # torch's CPU ops stop scaling (and then collapse) well below the box's 128-256 hardware threads on this op mix:
-        # measured on the GPU box (tools/cpu_baseline_sweep.py) 16 threads x B=1 is the fastest, 128 threads 10x slower.
+        # measured on the GPU box (tests/extra/cpu_baseline_sweep.py) 16 threads x B=1 is the fastest, 128 threads 10x slower.
         ncpu = os.cpu_count() or 1
         for th in sorted({min(16, ncpu), min(32, ncpu)}):
             torch.set_num_threads(th)

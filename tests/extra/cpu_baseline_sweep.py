@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which torch thread count / batch gives the fastest CPU restatement on this host (input for bench.py's cpu_baseline)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import transformer_oracle as O
 from oracle.torch_restatement import TorchTrainer

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """One-off fuzzing of the attention kernels (forward, dQ, dK/dV, fused bias sums) through the kernel-level parity check of
-tests/test_gpu_kernels.py on random shapes:  python tools/fuzz_attention.py [N] [seed]   (COMPOSER_ATTN64 selects the opt-in forwards)"""
+tests/test_gpu_kernels.py on random shapes:  python tests/extra/fuzz_attention.py [N] [seed]   (COMPOSER_ATTN64 selects the opt-in forwards)"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_kernels as K
 

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""One-off fuzzing of cmp_k_gemm against float64 (GPU box only):  python tools/fuzz_gemm.py [N] [seed]
+"""One-off fuzzing of cmp_k_gemm against float64 (GPU box only):  python tests/extra/fuzz_gemm.py [N] [seed]
 Random dtype, operand layouts, M / N / K (tiny to a few thousand, ragged), leading-dimension padding, kernel-selection flags,
 epilogue (bias, gelu with the pre-activation output, gelu' of an auxiliary input, residual, dropout) or split-K accumulation.
 The reference is built from the SAME rounded operands; dropout masks come from the oracle's restatement of the counter hash."""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import transformer_oracle as O
 import test_gpu_kernels as K

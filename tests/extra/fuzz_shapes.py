@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """One-off fuzzing of the model configuration domain against the float64 oracle (test infrastructure, GPU box only):
-    python tools/fuzz_shapes.py [N] [seed]
+    python tests/extra/fuzz_shapes.py [N] [seed]
 Every case draws vocabulary, width, heads (any head size up to 128), blocks, window, T, B, the constructor switches, dropout and
 dtype, then compares one training-mode loss + all gradients, the inference logits, presents and a short greedy decode (fp32) with
 the oracle.  Prints the failing configurations; exit code = number of failures.  The committed tests hold seeded samples of
 the same generator's ranges (tests/test_gpu_round3.py)."""
 import os, sys, traceback
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import transformer_oracle as O
 from composer_amd import _lib

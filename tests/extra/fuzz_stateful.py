@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off STATEFUL fuzzing against the float64 oracle (GPU box only):  python tools/fuzz_stateful.py [models] [ops] [seed]
+"""One-off STATEFUL fuzzing against the float64 oracle (GPU box only):  python tests/extra/fuzz_stateful.py [models] [ops] [seed]
 One fp32 model per round (random configuration incl. odd head sizes, dropout on), then a random sequence of operations whose
 results are each compared with an oracle that is re-synchronised to the model's full state (weights, both Adam moments,
 iteration count) before every operation -- so every comparison is a one-operation comparison, and anything stale inside the
@@ -10,7 +10,7 @@ loop's staging slots, dropout streams keyed on the iteration) shows up:
 FUZZ_DP=1: every model joins a 1-rank RCCL communicator first (the data-parallel code path of the train step)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import transformer_oracle as O
 from composer_amd import _lib

@@ -6,7 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from composer_amd.transformer import Transformer
-from oracle import transformer_oracle as O
+
+
+def synthetic_batch(rng, V, B, T):
+    seq = rng.integers(0, V, size=(B, T + 1), dtype=np.int32)
+    return np.ascontiguousarray(seq[:, :-1]), np.ascontiguousarray(seq[:, 1:])
 
 WHAT = os.environ.get("LEAK_WHAT", "train,async,eval,fwd,gen,dp").split(",")      # which uses to include (to localise a leak)
 
@@ -31,7 +35,7 @@ def one(i):
     V, E, H, L, W, B = 390, 128, 4, 2, 64, 4
     m = Transformer(V, E, W, L, H, dtype="bf16" if i % 2 else "fp32", seed=i, max_batch=B, max_seq=W)
     m.initialize_parameters(i)
-    x, y = O.synthetic_batch(np.random.default_rng(i), V, B, W)
+    x, y = synthetic_batch(np.random.default_rng(i), V, B, W)
     if "train" in WHAT: m.train_step(x, y, 1e-3)
     if "async" in WHAT:
         t = m.train_step_async(x, y, 1e-3); m.step_metrics(t)

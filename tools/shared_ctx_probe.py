@@ -6,7 +6,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from composer_amd.transformer import Transformer
-from oracle import transformer_oracle as O
+
+
+def synthetic_batch(rng, V, B, T):
+    seq = rng.integers(0, V, size=(B, T + 1), dtype=np.int32)
+    return np.ascontiguousarray(seq[:, :-1]), np.ascontiguousarray(seq[:, 1:])
 
 
 def run(shared):
@@ -22,7 +26,7 @@ def run(shared):
     for i in range(60):
         for k, m in enumerate(ms):
             V, E, H, L, W, B, dt = cfgs[k]
-            x, y = O.synthetic_batch(rngs[k], V, B, W)
+            x, y = synthetic_batch(rngs[k], V, B, W)
             res.append(m.train_step(x, y, 1e-3)[0])
             if i % 4 == k:
                 res.extend(m.generate(x[0, :6], 5, temperature=0.0, mode="kv").tolist())

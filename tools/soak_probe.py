@@ -7,7 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from composer_amd.transformer import Transformer
-from oracle import transformer_oracle as O
+
+
+def synthetic_batch(rng, V, B, T):
+    seq = rng.integers(0, V, size=(B, T + 1), dtype=np.int32)
+    return np.ascontiguousarray(seq[:, :-1]), np.ascontiguousarray(seq[:, 1:])
 
 
 def rss():
@@ -23,7 +27,7 @@ def main():
     rng = np.random.default_rng(0)
     def body(i):
         T = int(rng.integers(1, W + 1)); Bq = int(rng.integers(1, B + 1))
-        x, y = O.synthetic_batch(rng, V, Bq, T)
+        x, y = synthetic_batch(rng, V, Bq, T)
         m.train_step(x, y, 1e-3)
         t = m.train_step_async(x, y, 1e-3); m.step_metrics(t)
         if i % 4 == 0: m.evaluate([(x, y)])

@@ -7,7 +7,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from composer_amd.transformer import Transformer
-from oracle import transformer_oracle as O
+
+
+def synthetic_batch(rng, V, B, T):
+    seq = rng.integers(0, V, size=(B, T + 1), dtype=np.int32)
+    return np.ascontiguousarray(seq[:, :-1]), np.ascontiguousarray(seq[:, 1:])
 
 
 def work(tag, steps, out):
@@ -27,7 +31,7 @@ def work_(tag, steps, out):
         m.initialize_parameters(3 + gen)
         rng = np.random.default_rng(7 + gen)
         for i in range(steps):
-            x, y = O.synthetic_batch(rng, V, B, W)
+            x, y = synthetic_batch(rng, V, B, W)
             res.append(m.train_step(x, y, 1e-3)[0])
             if i % 5 == 0:
                 res.append(float(m.evaluate([(x, y)])[0]))
