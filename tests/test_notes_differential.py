@@ -1,0 +1,89 @@
+"""CPU only, build container only: `composer_amd.notes` and the id codec of `composer_amd.dataset` against the REFERENCE's own
+composer/dataset/sequence.py imported live (the same import shims as tests/golden/make_notes_golden.py) on a few thousand seeded
+random note sequences -- the committed `notes.npz` holds 96 cases of this generator; where /root/reference does not exist (the GPU
+box) the test is skipped and the committed vectors stand alone."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from composer_amd import dataset as ds
+from composer_amd.notes import Note, NoteSequence, SustainPeriod
+
+REF = "/root/reference/composer"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+
+
+def _reference_module():
+    np.int, np.float = int, float                      # the reference predates numpy 1.24
+    saved = {k: sys.modules.get(k) for k in ("pretty_midi", "composer", "composer.dataset", "composer.dataset.sequence")}
+    pm = types.ModuleType("pretty_midi")
+    for n in ("PrettyMIDI", "Instrument", "Note", "ControlChange"):
+        setattr(pm, n, type(n, (), {}))
+    sys.modules["pretty_midi"] = pm
+    pkg = types.ModuleType("composer"); pkg.__path__ = [REF]
+    sys.modules["composer"] = pkg
+    try:
+        import composer.dataset.sequence as S
+        return S
+    finally:
+        for k, v in saved.items():                     # leave no stand-in behind for other tests
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _random_case(rng):
+    settings = [(10, 100, 32), (10, 100, 4), (20, 50, 16), (5, 100, 8), (5, 1000, 64), (1, 200, 128)][int(rng.integers(0, 6))]
+    frac = bool(rng.integers(0, 2))
+    nn = int(rng.integers(0, 30))
+    notes = []
+    for _ in range(nn):
+        st = float(rng.uniform(0, 20000)) if frac else float(int(rng.integers(0, 2000)) * 10)
+        du = float(rng.uniform(0, 3000)) if frac else float(int(rng.integers(0, 300)) * 10)
+        if rng.random() < 0.1:
+            du = 0.0
+        notes.append((st, st + du, int(rng.integers(0, 128)) if rng.random() < 0.5 else int(rng.integers(58, 64)), int(rng.integers(1, 128))))
+    periods, t = [], float(rng.uniform(0, 1500))
+    for _ in range(int(rng.integers(0, 4))):
+        d = float(rng.uniform(100, 4000)) if frac else float(int(rng.integers(10, 400)) * 10)
+        periods.append((t, t + d))
+        t += d + (float(rng.uniform(50, 3000)) if frac else float(int(rng.integers(5, 300)) * 10))
+    return settings, notes, periods
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_notes_and_ids_equal_the_reference_module_on_random_sequences(seed):
+    S = _reference_module()
+    modes = {"events": S.NoteSequence.SustainPeriodEncodeMode.EVENTS, "none": S.NoteSequence.SustainPeriodEncodeMode.NONE,
+             "extend": S.NoteSequence.SustainPeriodEncodeMode.EXTEND}
+    rng = np.random.default_rng(seed)
+    events_checked = 0
+    for case in range(400):
+        (tsi, mts, vb), notes, periods = _random_case(rng)
+        trim = bool(rng.integers(0, 2)) and len(notes) > 0
+        for mode in ("events", "none", "extend"):
+            for clean in ((True, False) if mode == "events" else (True,)):
+                ref = S.NoteSequence([S.Note(*n) for n in notes], [S.SustainPeriod(*p) for p in periods])
+                mine = NoteSequence([Note(*n) for n in notes], [SustainPeriod(*p) for p in periods])
+                if trim:
+                    ref.trim_start(); mine.trim_start()
+                    assert [(n.start, n.end) for n in mine.notes] == [(n.start, n.end) for n in ref.notes]
+                es = ref.to_event_sequence(tsi, mts, vb, modes[mode], clean)
+                want = [(int(e.type), None if e.value is None else int(e.value)) for e in es.events]
+                got = mine.to_events(tsi, mts, vb, sustain=mode, clean=clean)
+                assert got == want, (seed, case, mode, clean)
+                vr = ds.event_value_ranges(tsi, mts, vb); rg = ds.event_ranges(vr)
+                ids = [ds.event_to_id(t, v, rg, vr) for t, v in got]
+                assert ids == [S.IntegerEncodedEventSequence.event_to_id(e.type, e.value, es.event_ranges, es.event_value_ranges) for e in es.events]
+                assert [ds.id_to_event(i, rg, vr) for i in ids] == got
+                assert ds.vocab_size(tsi, mts, vb) == max(r.stop for r in es.event_ranges.values())
+                back_ref = es.to_note_sequence()
+                back = NoteSequence.from_events(got, tsi, vb)
+                assert [(n.start, n.end, n.pitch, n.velocity) for n in back.notes] == [(n.start, n.end, n.pitch, n.velocity) for n in back_ref.notes]
+                assert [(s.start, s.end) for s in back.sustain_periods] == [(s.start, s.end) for s in back_ref.sustain_periods]
+                events_checked += len(got)
+    assert events_checked > 100_000
