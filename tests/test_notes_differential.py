@@ -87,3 +87,29 @@ def test_notes_and_ids_equal_the_reference_module_on_random_sequences(seed):
                 assert [(s.start, s.end) for s in back.sustain_periods] == [(s.start, s.end) for s in back_ref.sustain_periods]
                 events_checked += len(got)
     assert events_checked > 100_000
+
+
+def test_data_files_equal_the_reference_writer_and_reader(tmp_path):
+    """`.data` files (sequence.py:1500-1560): for random codec settings and event lists, the bytes written by `write_data_file` equal
+    the reference's `IntegerEncodedEventSequence.to_file`, and `read_data_file` returns the ids of its `event_ids_from_file` -- 60
+    files incl. an empty one, beyond the two whose bytes are committed in tests/golden/codec.npz."""
+    S = _reference_module()
+    rng = np.random.default_rng(11)
+    for k in range(60):
+        settings = (int(rng.choice([1, 2, 5, 10, 20])), int(rng.choice([50, 100, 200, 1000])), int(rng.choice([4, 8, 32, 64, 128])))
+        if settings[1] % settings[0]:
+            continue
+        vr = S.EventSequence._compute_event_value_ranges(*settings)
+        types_ = list(vr.keys())
+        events = []
+        for _ in range(0 if k == 7 else int(rng.integers(1, 400))):
+            t = types_[int(rng.integers(0, len(types_)))]
+            v = S.Event.NONE_VALUE if vr[t] is None else int(rng.integers(vr[t].start, vr[t].stop))
+            events.append((int(t), v))
+        ref_path, my_path = str(tmp_path / ("r%d.data" % k)), str(tmp_path / ("m%d.data" % k))
+        S.IntegerEncodedEventSequence(settings[0], settings[1], settings[2], events).to_file(ref_path)
+        ds.write_data_file(my_path, [(t, None if v == S.Event.NONE_VALUE else v) for t, v in events], *settings)
+        assert open(my_path, "rb").read() == open(ref_path, "rb").read(), (k, settings)
+        ids_ref, _, _, st = S.IntegerEncodedEventSequence.event_ids_from_file(ref_path)
+        ids, st_mine = ds.read_data_file(ref_path)
+        assert list(ids) == list(ids_ref) and tuple(st_mine) == tuple(st), (k, settings)
