@@ -33,6 +33,30 @@ use_layer_normalization: true
     assert c.filepath == cli.get_default_config()
 
 
+def test_config_objects_behave_like_mappings_and_like_attributes(tmp_path):
+    import copy
+    import pickle
+    f = tmp_path / "two_docs.yml"
+    f.write_text("a: {b: {c: 1}, l: [{x: 2}]}\nk: 1\n---\nk: 2\n---\n")       # later documents win; an empty document is skipped
+    c = config.get(f)
+    assert c.a.b.c == 1 and c["a"]["b"]["c"] == 1 and c.a.l[0].x == 2 and c.k == 2
+    assert c.a.get("missing", 7) == 7 and c.get("a") is c.a
+    c.a.b.new = {"deep": {"er": 3}}                      # assignment through either notation wraps nested mappings
+    c["z"] = {"y": 4}
+    assert c.a.b.new.deep.er == 3 and c.z.y == 4
+    del c.z
+    assert "z" not in c and not hasattr(c, "z")          # a missing key is an AttributeError, not a KeyError
+    with pytest.raises(AttributeError):
+        c.nope
+    with pytest.raises(KeyError):
+        c["nope"]
+    assert "filepath" not in c and c.filepath == f       # where the file came from is not a configuration key
+    for d in (copy.deepcopy(c), pickle.loads(pickle.dumps(c))):
+        assert d == c and d.filepath == f and d.a.b.c == 1 and isinstance(d, config.ConfigInstance)
+    assert yaml.safe_load(yaml.safe_dump(c.to_dict())) == c.to_dict() and type(c.to_dict()["a"]) is dict
+    assert config.Dotdict({"a": 1}, b=2) == {"a": 1, "b": 2} and config.Dotdict().setdefault("q", {"r": 1}).r == 1
+
+
 def test_cli_commands_and_defaults():
     r = CliRunner()
     out = r.invoke(cli.cli, ["--help"]).output
