@@ -53,6 +53,14 @@ void prof_stop(int cls, hipStream_t s, double work);
 
 // Per-launch extras of the GEMM launcher (gemm.hip: gemm_run) that the C ABI's cmp_k_gemm does not carry.  The model driver
 // fills one per call, so nothing about a launch lives in process-wide state.
+// Item-counter workspace of the persistent GEMM kernels (gemm.hip: ItemPuller / sched_next): two alternating counter sets on
+// the device.  One per cmp_ctx (allocated on first use, freed by cmp_ctx_destroy); launches that arrive without a context
+// (cmp_k_gemm) use a process-wide table keyed by (device, stream) under a lock that is held across the launch.
+struct SchedWs {
+    uint32_t* dev = nullptr;
+    int parity = 0;
+    bool dirty = false;          // a launch that used the counters failed: both sets are re-zeroed before the next use
+};
 struct GemmExtra {
     float* colsum = nullptr;     // also add the column sums of the output to colsum[0..N) (the bias gradient that goes with an
                                  // input-gradient GEMM); fused into the epilogue where possible, else a colsum pass after it
@@ -61,6 +69,7 @@ struct GemmExtra {
     int role = -1;               // cmp_prof_* timing class: 0 forward, 1 dgrad, 2 wgrad, -1 = by operand layout
     int max_wgs = 0;             // cap on the persistent kernels' grid (CUs left to a concurrent RCCL kernel); 0 = all 256
     bool dp = false;             // the launch belongs to a data-parallel job: persistent kernels hand their items out dynamically
+    SchedWs* sched = nullptr;    // the calling context's item-counter workspace (a cmp_ctx is single-threaded by contract: no lock)
 };
 int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* Bm, int ldb,
              void* C, int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,

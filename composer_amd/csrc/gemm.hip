@@ -1683,33 +1683,47 @@ static void launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M,
 #include <mutex>
 #include <map>
 #define CHECK_SCHED(expr) do { int rc_ = (expr); if (rc_ != CMP_OK) return rc_; } while (0)
-struct SchedWs { uint32_t* dev = nullptr; int parity = 0; };
-static int sched_next(hipStream_t s, Epilogue& ep, bool dp) {
+// `held` keeps the process-wide table's lock until the launch has been issued (two threads driving one stream through
+// cmp_k_gemm must launch in the order of their parity draws); a context's own workspace (ex.sched) needs no lock.
+static int sched_next(hipStream_t s, Epilogue& ep, const GemmExtra& ex, std::unique_lock<std::mutex>& held, SchedWs** used) {
     // default: counters when the launch belongs to a data-parallel job (a communicator exists: RCCL kernels may hold CUs), static
     // striding otherwise (undisturbed, the counters cost 0-1.3 % -- an extra barrier and LDS word per item);
     // COMPOSER_GEMM_ITEMS=dynamic / static (read per call) overrides
     const char* e = getenv("COMPOSER_GEMM_ITEMS");
-    const bool dyn = e ? e[0] == 'd' : dp;
+    const bool dyn = e ? e[0] == 'd' : ex.dp;
     ep.sched = ep.sched_clear = nullptr;
+    *used = nullptr;
     if (!dyn) return CMP_OK;
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, SchedWs> tab;
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
     // inside a stream capture the launch is replayed with frozen arguments: the alternation of the two counter sets would not
     // survive a replay, so captured launches stride statically
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return CMP_OK;
-    SchedWs& w = tab[std::make_pair(dev, s)];
-    if (!w.dev) {
-        HIP_CHECK(hipMalloc((void**)&w.dev, 2 * SCHED_SET_WORDS * 4));
-        HIP_CHECK(hipMemsetAsync(w.dev, 0, 2 * SCHED_SET_WORDS * 4, s));      // on the launch's own stream: no legacy-stream call (another thread may be capturing)
+    SchedWs* w = ex.sched;
+    if (!w) {
+        static std::mutex mu;
+        static std::map<std::pair<int, hipStream_t>, SchedWs> tab;
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        held = std::unique_lock<std::mutex>(mu);
+        w = &tab[std::make_pair(dev, s)];
     }
-    ep.sched = w.dev + w.parity * SCHED_SET_WORDS;
-    ep.sched_clear = w.dev + (w.parity ^ 1) * SCHED_SET_WORDS;
-    w.parity ^= 1;
+    if (!w->dev) {
+        HIP_CHECK(hipMalloc((void**)&w->dev, 2 * SCHED_SET_WORDS * 4));
+        w->dirty = true;
+    }
+    if (w->dirty) {     // first use, or the previous launch on these counters failed before it could zero the other set
+        HIP_CHECK(hipMemsetAsync(w->dev, 0, 2 * SCHED_SET_WORDS * 4, s));      // on the launch's own stream: no legacy-stream call (another thread may be capturing)
+        w->parity = 0;
+        w->dirty = false;
+    }
+    ep.sched = w->dev + w->parity * SCHED_SET_WORDS;
+    ep.sched_clear = w->dev + (w->parity ^ 1) * SCHED_SET_WORDS;
+    w->parity ^= 1;
+    *used = w;
     return CMP_OK;
+}
+void sched_ws_free(SchedWs* w) {
+    if (w && w->dev) { (void)hipFree(w->dev); w->dev = nullptr; }
 }
 
 extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda,
@@ -1735,6 +1749,8 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
     float* const g_slab_ws = ex.slab_ws;
     const size_t g_slab_bytes = ex.slab_ws ? ex.slab_bytes : 0;
     const int g_gemm_role = ex.role;
+    std::unique_lock<std::mutex> sched_lock;         // held from the counter-set draw to the launch (process-wide table only)
+    SchedWs* sched_used = nullptr;
     Epilogue ep;
     ep.bias = bias;
     ep.act = act;
@@ -1805,7 +1821,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             // split-K: partial slabs + reduce when the registered workspace is large enough, else f32 atomics
             const bool slabs = ep.atomic && nsplit > 1 && ldc == N && (N % 4 == 0) && g_slab_ws &&
                                (size_t)nsplit * M * N * 4 <= g_slab_bytes && !(flags & 128);
-            CHECK_SCHED(sched_next(s, ep, ex.dp));
+            CHECK_SCHED(sched_next(s, ep, ex, sched_lock, &sched_used));
             Epilogue ep2 = ep;
             if (slabs) ep2.atomic = 0;
             const bool swap = !ep2.atomic;
@@ -1826,7 +1842,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             const int g1 = std::min(ntiles * nsplit, max_wgs);
             const bool swap = !ep.atomic;
             ep.colsum = colsum_out;
-            CHECK_SCHED(sched_next(s, ep, ex.dp));
+            CHECK_SCHED(sched_next(s, ep, ex, sched_lock, &sched_used));
             if (!ta && !tb) colsum_fused = launch_256<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
             else if (!ta && tb) colsum_fused = launch_256<true, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
             else if (ta && !tb) colsum_fused = launch_256<false, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
@@ -1847,7 +1863,15 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
         else gemm_bf16_kernel<false, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
         PROF_STOP(cls, s, 2.0 * M * N * K);
     }
-    KERNEL_CHECK();
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            if (sched_used) sched_used->dirty = true;      // the launch never ran: it did not zero the other counter set
+            cmp_set_error("%s:%d: gemm launch failed: %s", __FILE__, __LINE__, hipGetErrorString(le));
+            return CMP_ERR_HIP;
+        }
+    }
+    if (sched_lock.owns_lock()) sched_lock.unlock();
     if (colsum_out && !colsum_fused) return cmp_k_colsum(stream, C, ldc, colsum_out, M, N, dtype);
     return CMP_OK;
 }

@@ -41,7 +41,9 @@ struct cmp_ctx {
     uint32_t seed_mix = 0;              // mix32(rank), xor-ed into every dropout seed: replicas draw independent masks
     int gemm_max_wgs = 0;               // cap on the persistent GEMM grids while a communicator exists (0 = all CUs)
     hipStream_t copy_stream = nullptr;  // host -> device id uploads of the pipelined train loop
+    SchedWs gemm_sched;                 // item counters of the persistent GEMMs launched on `stream` (gemm.hip: sched_next)
 };
+void sched_ws_free(SchedWs* w);
 
 struct ParamInfo {
     std::string name;

@@ -137,6 +137,7 @@ extern "C" int cmp_ctx_destroy(cmp_ctx* c) {
     hipStreamSynchronize(c->comm_stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    sched_ws_free(&c->gemm_sched);
     hipStreamDestroy(c->stream);
     hipStreamDestroy(c->comm_stream);
     hipStreamDestroy(c->copy_stream);
@@ -191,13 +192,12 @@ __global__ __launch_bounds__(1024) void cu_hog_kernel(unsigned long long ticks, 
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (big[(threadIdx.x * 7) & 16383] == -1) *sink = 1;
+    if (sink && big[(threadIdx.x * 7) & 16383] == -1) *sink = 1;      // (keeps the LDS array alive; sink is null)
 }
 extern "C" int cmp_dp_test_hog(cmp_ctx* c, int wgs, int usec) {
     CMP_REQUIRE(c && wgs > 0 && wgs <= 256 && usec > 0 && usec <= 1000000, "dp_test_hog: bad arguments");
-    static int* sink = nullptr;
-    if (!sink) HIP_CHECK(hipMalloc((void**)&sink, 16));
-    cu_hog_kernel<<<wgs, 1024, 0, c->comm_stream>>>((unsigned long long)usec * 100ull, sink);
+    HIP_CHECK(hipSetDevice(c->device));
+    cu_hog_kernel<<<wgs, 1024, 0, c->comm_stream>>>((unsigned long long)usec * 100ull, nullptr);
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -245,6 +245,7 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     CMP_REQUIRE(V > 0 && E > 0 && W > 0 && L > 0 && H > 0, "model_create: sizes must be positive");
     CMP_REQUIRE(E % H == 0, "model_create: embedding_size %d not divisible by heads %d (transformer.py:255)", E, H);
     CMP_REQUIRE(E % 8 == 0, "model_create: embedding_size %d must be a multiple of 8", E);
+    CMP_REQUIRE(E <= 2048, "model_create: embedding_size %d unsupported (at most 2048: LayerNorm rows, per-token decode rows of 4E)", E);
     const int Dl = E / H;
     CMP_REQUIRE(Dl <= 128, "model_create: head size %d unsupported (at most 128)", Dl);
     const int D = Dl <= 16 ? 16 : (Dl <= 32 ? 32 : (Dl <= 64 ? 64 : 128));     // the attention kernels' head sizes; Dl < D: zero-padded columns
@@ -612,6 +613,7 @@ static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A
     ex.role = m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1);         // forward announces 0; backward: A^T = wgrad, else dgrad
     ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;              // leave CUs to the concurrent all-reduce kernels
     ex.dp = m->ctx->comm != nullptr;                                   // RCCL kernels may hold CUs: dynamic item scheduling
+    ex.sched = &m->ctx->gemm_sched;
     CHECK_RC(gemm_run(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
                       out_fp32, splitk, p_drop, m->drop_seed(), rng_stream, flags, ex));
     if (det && colsum) CHECK_RC(colsum_det(m, C, ldc, colsum, M, N));

@@ -51,7 +51,7 @@ typedef struct cmp_model_cfg {
     int32_t embedding_size;    /* E, multiple of 8 */
     int32_t window_size;       /* W = rows of wpe */
     int32_t layers;            /* L  */
-    int32_t heads;             /* H, E % H == 0 (transformer.py:255), E/H in {16,32,64,128} */
+    int32_t heads;             /* H, E % H == 0 (transformer.py:255), head size E/H <= 128 (see cmp_model_create) */
     float   ln_eps;            /* layer_normalization_epsilon */
     int32_t scale_attention;   /* `scale` */
     int32_t use_layer_norm;    /* `use_layer_normalization` */

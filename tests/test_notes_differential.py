@@ -17,7 +17,12 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tr
 
 
 def _reference_module():
-    np.int, np.float = int, float                      # the reference predates numpy 1.24
+    # the reference predates numpy 1.24: `np.int` / `np.float` appear as DEFAULT ARGUMENTS (sequence.py:1347,1643,1733,1795), i.e.
+    # they are read once, while the module is imported -- the aliases exist for that import only and are taken away again
+    # so that no other test of the session can lean on them
+    missing = object()
+    np_saved = {k: np.__dict__.get(k, missing) for k in ("int", "float")}
+    np.int, np.float = int, float
     saved = {k: sys.modules.get(k) for k in ("pretty_midi", "composer", "composer.dataset", "composer.dataset.sequence")}
     pm = types.ModuleType("pretty_midi")
     for n in ("PrettyMIDI", "Instrument", "Note", "ControlChange"):
@@ -29,6 +34,11 @@ def _reference_module():
         import composer.dataset.sequence as S
         return S
     finally:
+        for k, v in np_saved.items():
+            if v is missing:
+                np.__dict__.pop(k, None)
+            else:
+                setattr(np, k, v)
         for k, v in saved.items():                     # leave no stand-in behind for other tests
             if v is None:
                 sys.modules.pop(k, None)

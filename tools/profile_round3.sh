@@ -24,7 +24,6 @@ timeout 300 python tools/decode_bench.py > $out/decode_bench.txt 2>&1
 COMPOSER_DECODE_V1=1 timeout 300 python tools/decode_bench.py > $out/decode_bench_v1.txt 2>&1
 timeout 300 python tools/decode_diag.py > $out/decode_diag.txt 2>&1
 timeout 300 ./tools/ubench/bin/graph_chain > $out/graph_chain.txt 2>&1
-DECODE_EAGER_ONLY= timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_decode -o k -- python3 tools/decode_bench.py > $out/stats_decode.log 2>&1
 timeout 900 python tools/train_cli_bench.py > $out/train_cli.txt 2>&1; cat $out/train_cli.txt
 # persistent-GEMM item scheduling: static vs counters, plain / beside a CU hog / 1-rank communicator with and without the CU cap
 timeout 900 tools/ab_sched.sh $tag
