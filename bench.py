@@ -16,9 +16,12 @@ Inputs are generated up front and live in HBM before the timed region.
 
 One JSON line on rank 0 with `roofline` (live HIP-event timing of the dominant kernel class inside the timed
 region), `cpu_baseline` (the CPU restatement of the reference path on the host cores, bounded sample; N=1 only),
-`decode` (BASELINE config 5, with its own memory roofline) and, at N=1, three more driver-timed objects: `classes` (the live
-roofline of EVERY kernel class of the step, three extra steps each), `b32` (SURVEY's C2 batch, 32 sequences) and `c4` (BASELINE
-config 4), each `{ms_per_step, value, model_mfma_frac}` from 3 warm-up + 10 timed steps.
+`decode` (BASELINE config 5, with its own memory roofline) and, at N=1, more driver-timed objects: `classes` (the live
+roofline of EVERY kernel class of the step, three extra steps each; every entry carries `algorithmic_bytes` and, when
+profiles/hbm_traffic.json covers the run, the PMC-measured in-step `traffic`), `b32` (SURVEY's C2 batch, 32 sequences, with its
+own `classes`) and `c4` (BASELINE config 4), each `{ms_per_step, value, model_mfma_frac}` from 3 warm-up + 10 timed steps, and
+`forward` (the north-star quantity: the inference forward pass of C2 and C4 as a fraction of the bf16 MFMA peak).
+Under a launcher (any N, also 1) the line carries `comm`: the gradient exchange's exposed (non-overlapped) time per step.
 """
 import argparse
 import ctypes as C
@@ -54,20 +57,82 @@ KERNEL_CLASSES = {
     5: ("attn_dkv_kernel<bf16,64>", "mfma"),
     6: ("layernorm_fwd_kernel<bf16>", "hbm"),
     7: ("adam_kernel", "hbm"),
+    8: ("layernorm_bwd_kernel<bf16> (+ residual add, masked copy, bias-gradient column sums)", "hbm"),
 }
 
 
 def pmc_traffic(kernel_class, tokens, cfg_name):
-    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/hbm_traffic.json, made by
-    tools/profile_round.sh + tools/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, gfx950
+    """HBM-side bytes per launch of a kernel class INSIDE THE TRAIN STEP, from the committed PMC passes over this very script
+    (profiles/hbm_traffic.json, made by tools/profile_round4.sh + tools/make_traffic_json.py: `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` in separate runs of `python3 bench.py --no-extras --no-cpu-baseline --no-decode`, the gfx950 FETCH_SIZE
     correction applied).  Counters cannot be read from inside this process; None when the file does not cover the run."""
     try:
         doc = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     except Exception:
         return None
-    if kernel_class != 0 or cfg_name != doc.get("config", "c2") or tokens != doc.get("tokens_per_launch"):
+    run = doc.get("runs", {}).get("%s_tokens%d" % (cfg_name, tokens))
+    if not run:
         return None
-    return doc.get("class0_forward_gemm_mean_bytes_per_launch")
+    ent = run.get("classes", {}).get(str(kernel_class))
+    return ent.get("traffic_bytes_per_launch") if ent else None
+
+
+def class_table(lib, step, tokens, cfg_name, reps=3):
+    """Live roofline of every kernel class of the step: HIP events around each launch of the class on its own stream
+    (cmp_prof_*), `reps` steps per class, outside the timed region."""
+    rows = []
+    for cls in sorted(KERNEL_CLASSES):
+        lib.cmp_prof_begin(cls)
+        for i in range(reps):
+            step(i)
+        cms, cn, cw, cb = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        lib.cmp_prof_end2(C.byref(cms), C.byref(cn), C.byref(cw), C.byref(cb))
+        if cn.value <= 0 or cms.value <= 0:
+            continue
+        nm, bound = KERNEL_CLASSES[cls]
+        rate = cw.value / (cms.value * 1e-3)
+        peak = PEAK_BF16_TFLOPS * 1e12 if bound == "mfma" else PEAK_HBM_GBS * 1e9
+        row = {"class": cls, "kernel": nm.split(" (")[0], "bound": bound, "launches_per_step": cn.value // reps,
+               "avg_us": 1e3 * cms.value / cn.value, "ms_per_step": cms.value / reps,
+               "achieved": rate / (1e12 if bound == "mfma" else 1e9), "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+               "frac": rate / peak, "algorithmic_bytes": cb.value / cn.value, "traffic": pmc_traffic(cls, tokens, cfg_name)}
+        if row["traffic"]:
+            row["traffic_over_algorithmic"] = row["traffic"] / row["algorithmic_bytes"]
+            row["hbm_gbs"] = row["traffic"] / (row["avg_us"] * 1e-6) / 1e9
+        rows.append(row)
+    return rows
+
+
+def forward_bench(device):
+    """north_star: "fraction of the bf16 MFMA peak on the attention+FFN forward at seq=1024".  The inference forward pass
+    (cmp_eval_step: embed -> L blocks -> ln_f -> tied logits -> loss; dropout off, the ids upload and the call's sync included,
+    < 1 %) of C2 at B=128 and C4 at B=32, median of 20 calls.  FLOPs per token = L*(24E^2 + 2ET) + 2EV (causal attention on the
+    unmasked half); `frac_attn_ffn` leaves the logits GEMM's FLOPs out of the numerator (time unchanged)."""
+    from composer_amd.transformer import Transformer
+    out = {}
+    for name in ("c2", "c4"):
+        cf = CONFIGS[name]
+        E, H, L, T, B = cf["E"], cf["H"], cf["L"], cf["T"], cf["B"]
+        m = Transformer(V, E, T, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="bf16", seed=0, max_batch=B,
+                        max_seq=T, device=device)
+        m.initialize_parameters(0)
+        rng = np.random.default_rng(0)
+        ds = [(rng.integers(0, V, (B, T), dtype=np.int32), rng.integers(0, V, (B, T), dtype=np.int32))]
+        for _ in range(3):
+            m.evaluate(ds)
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            m.evaluate(ds)
+            ts.append(time.perf_counter() - t0)
+        m.close()
+        dt = float(np.median(ts))
+        blocks = L * (24 * E * E + 2 * E * T)
+        tf = B * T * (blocks + 2 * E * V) / dt / 1e12
+        out[name] = {"workload": "%s inference forward, seq=%d, B=%d, bf16" % (cf["label"], T, B), "ms": 1e3 * dt,
+                     "tokens_per_s": B * T / dt, "tflops": tf, "frac": tf / PEAK_BF16_TFLOPS,
+                     "frac_attn_ffn": B * T * blocks / dt / 1e12 / PEAK_BF16_TFLOPS}
+    return out
 
 
 class stdout_to_stderr:
@@ -182,7 +247,7 @@ def decode_bench(device):
                          "note": "fp32 weights %.1f MB + mean K/V cache read %.2f MB per token" % (weight_bytes / 1e6, kv_bytes / 1e6)}}
 
 
-def side_config(name, Bq, device, dropout, steps=10, warmup=3):
+def side_config(name, Bq, device, dropout, steps=10, warmup=3, classes=False):
     """A short timed run of another configuration on the same GPU (N=1): 3 warm-up + 10 steps, inputs resident in HBM."""
     import torch
     from composer_amd.transformer import Transformer
@@ -205,11 +270,19 @@ def side_config(name, Bq, device, dropout, steps=10, warmup=3):
     m.synchronize()
     dt = time.perf_counter() - t0
     loss, _ = m.last_metrics()
+    table = None
+    if classes:
+        from composer_amd import _lib
+        table = class_table(_lib.load(), lambda i: m.train_step_device(xs[i % 2].data_ptr(), ys[i % 2].data_ptr(), Bq, T, LR),
+                            Bq * T, name)
     m.close()
     value = Bq * T * steps / dt
-    return {"workload": "%s, seq=%d, B=%d, dropout %.2f" % (cf["label"], T, Bq, dropout), "steps": steps, "warmup": warmup,
-            "ms_per_step": 1e3 * dt / steps, "value": value, "unit": "tokens/s",
-            "model_mfma_frac": value * flops_per_token_train(E, L, T) / 1e12 / PEAK_BF16_TFLOPS, "final_loss": loss}
+    out = {"workload": "%s, seq=%d, B=%d, dropout %.2f" % (cf["label"], T, Bq, dropout), "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps, "value": value, "unit": "tokens/s",
+           "model_mfma_frac": value * flops_per_token_train(E, L, T) / 1e12 / PEAK_BF16_TFLOPS, "final_loss": loss}
+    if table is not None:
+        out["classes"] = table
+    return out
 
 
 def self_launch(args):
@@ -304,6 +377,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    if under_launcher:
+        model.dp_stats(reset=True)
     lib = _lib.load()
     lib.cmp_prof_begin(args.roofline_kernel)
     t0 = time.perf_counter()
@@ -311,27 +386,14 @@ def main():
         step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    ms, n_launch, work = C.c_double(), C.c_int64(), C.c_double()
-    lib.cmp_prof_end(C.byref(ms), C.byref(n_launch), C.byref(work))
+    ms, n_launch, work, abytes = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    lib.cmp_prof_end2(C.byref(ms), C.byref(n_launch), C.byref(work), C.byref(abytes))
     loss, acc = model.last_metrics()
+    comm = model.dp_stats() if under_launcher else None          # the timed steps' exposed gradient-exchange time
     # the live roofline of every kernel class of the step (outside the timed region: three more steps per class)
     classes = None
     if world == 1 and not args.no_extras:
-        classes = []
-        for cls in sorted(KERNEL_CLASSES):
-            lib.cmp_prof_begin(cls)
-            for i in range(3):
-                step(i)
-            cms, cn, cw = C.c_double(), C.c_int64(), C.c_double()
-            lib.cmp_prof_end(C.byref(cms), C.byref(cn), C.byref(cw))
-            if cn.value > 0 and cms.value > 0:
-                nm, bound = KERNEL_CLASSES[cls]
-                rate = cw.value / (cms.value * 1e-3)
-                peak = PEAK_BF16_TFLOPS * 1e12 if bound == "mfma" else PEAK_HBM_GBS * 1e9
-                classes.append({"kernel": nm.split(" (")[0], "bound": bound, "launches_per_step": cn.value // 3,
-                                "avg_us": 1e3 * cms.value / cn.value, "ms_per_step": cms.value / 3,
-                                "achieved": rate / (1e12 if bound == "mfma" else 1e9), "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                                "frac": rate / peak})
+        classes = class_table(lib, step, Bq * T, args.config)
     if dist.is_initialized():
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -347,15 +409,17 @@ def main():
                 roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args.roofline_kernel, Bq * T, args.config)}
                 if roof["traffic"] is not None:
-                    roof["traffic_note"] = ("HBM-side bytes per launch (mean of the four per-layer forward GEMMs), rocprofv3 PMC "
-                                            "FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json; algorithmic bytes 740 MB")
+                    roof["traffic_note"] = ("HBM-side bytes per launch of this class inside the train step (mean over its launches): "
+                                            "rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes over bench.py itself, "
+                                            "profiles/hbm_traffic.json")
             else:
                 achieved = work.value / (ms.value * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBS, "traffic": None}
             roof.update({"kernel": name, "launches": int(n_launch.value),
                          "avg_launch_us": 1e3 * ms.value / n_launch.value,
-                         "algorithmic_per_launch": work.value / n_launch.value})
+                         "algorithmic_per_launch": work.value / n_launch.value,
+                         "algorithmic_bytes": abytes.value / n_launch.value})
         else:
             roof = None
         fpt = flops_per_token_train(E, L, T)
@@ -379,13 +443,20 @@ def main():
             out["cpu_baseline"] = None
         if classes is not None:
             out["classes"] = classes
+        if comm is not None:
+            # exposed (non-overlapped) communication per step = how long the compute stream waited, at the end of the
+            # backward pass, for the communication stream (all-reduce + Adam of the buckets still in flight); rank 0's value
+            out["comm"] = {"exposed_ms": comm["exposed_ms"], "steps": comm["steps"], "bytes": comm["bytes"], "buckets": comm["buckets"],
+                           "ranks": world, "note": "fp32 gradient buckets (one per decoder block + ln_f + embeddings) and a 3-float "
+                           "metrics message, ncclAllReduce on a highest-priority side stream, Adam per bucket behind its all-reduce"}
     model.close()
     if rank == 0:
         if world == 1 and not args.no_extras:
             if not (args.config == "c2" and Bq == 32):
-                out["b32"] = side_config("c2", 32, local_rank, args.dropout)
+                out["b32"] = side_config("c2", 32, local_rank, args.dropout, classes=True)
             if args.config != "c4":
                 out["c4"] = side_config("c4", CONFIGS["c4"]["B"], local_rank, args.dropout)
+            out["forward"] = forward_bench(local_rank)
         if world == 1 and not args.no_decode:
             out["decode"] = decode_bench(local_rank)
         print(json.dumps(out), flush=True)

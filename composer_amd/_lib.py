@@ -49,6 +49,7 @@ SIGNATURES = {
     "cmp_dp_test_hog": (_i, [_P, _i, _i]),
     "cmp_dp_set_gemm_cus": (_i, [_P, _i]),
     "cmp_dp_set_mask_rank": (_i, [_P, _i]),
+    "cmp_dp_stats": (_i, [_P, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i)]),
     "cmp_model_create": (_i, [_P, C.POINTER(ModelCfg), C.POINTER(_P)]),
     "cmp_model_destroy": (_i, [_P]),
     "cmp_param_count": (_i, [_P, C.POINTER(_i)]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "cmp_k_sample": (_i, [_P, _P, _i, _f, _u64, _u32, _i, _P]),
     "cmp_prof_begin": (_i, [_i]),
     "cmp_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "cmp_prof_end2": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cmp_k_embed_fwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_embed_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_layernorm_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _f, _i]),

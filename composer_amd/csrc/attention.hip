@@ -1632,7 +1632,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
             PROF_START(3, s);
             if (d.thr) attn_fwd32d_kernel<true><<<grid, 256, smem4, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
             else attn_fwd32d_kernel<false><<<grid, 256, smem4, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
-            PROF_STOP(3, s, flops);
+            PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * 64 * 2 + 4.0));
             KERNEL_CHECK();
             return CMP_OK;
         }
@@ -1650,7 +1650,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
             PROF_START(3, s);
             if (d.thr) attn_fwd32p_kernel<true><<<grid, 256, smem3, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
             else attn_fwd32p_kernel<false><<<grid, 256, smem3, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
-            PROF_STOP(3, s, flops);
+            PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * 64 * 2 + 4.0));
             KERNEL_CHECK();
             return CMP_OK;
         }
@@ -1667,7 +1667,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
             PROF_START(3, s);
             if (d.thr) attn_fwd64_kernel<true><<<grid, 256, smem2, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
             else attn_fwd64_kernel<false><<<grid, 256, smem2, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
-            PROF_STOP(3, s, flops);
+            PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * 64 * 2 + 4.0));
             KERNEL_CHECK();
             return CMP_OK;
         }
@@ -1682,7 +1682,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
     PROF_START(3, s);
     if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
     else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
-    PROF_STOP(3, s, flops);
+    PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * D * sizeof(T) + 4.0));      // q, k, v in; o, lse out
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -1701,12 +1701,12 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
     PROF_START(4, s);
     if (d.thr) attn_dq_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
     else attn_dq_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
-    PROF_STOP(4, s, 3.0 * fl);
+    PROF_STOP(4, s, 3.0 * fl, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));       // q, k, v, o, dO, lse in; dQ, delta out
     KERNEL_CHECK();
     PROF_START(5, s);
     if (d.thr) attn_dkv_kernel<T, D, true><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
     else attn_dkv_kernel<T, D, false><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
-    PROF_STOP(5, s, 4.0 * fl);
+    PROF_STOP(5, s, 4.0 * fl, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));       // q, k, v, dO, lse, delta in; dK, dV out
     KERNEL_CHECK();
     return CMP_OK;
 }

@@ -47,9 +47,11 @@ void cmp_set_error(const char* fmt, ...);
 // live per-kernel-class timing (cmp_prof_begin / cmp_prof_end, model.hip)
 extern thread_local int g_prof_cls;
 void prof_start(int cls, hipStream_t s);
-void prof_stop(int cls, hipStream_t s, double work);
+void prof_stop(int cls, hipStream_t s, double work, double bytes);
+// work: the launch's algorithmic flops (matrix-core classes) or bytes (memory-bound classes); bytes: its algorithmic HBM
+// bytes -- every operand read once, every result written once (what the PMC traffic of profiles/ is compared with)
 #define PROF_START(cls, s) do { if (g_prof_cls == (cls)) prof_start((cls), (s)); } while (0)
-#define PROF_STOP(cls, s, work) do { if (g_prof_cls == (cls)) prof_stop((cls), (s), (work)); } while (0)
+#define PROF_STOP(cls, s, work, bytes) do { if (g_prof_cls == (cls)) prof_stop((cls), (s), (work), (bytes)); } while (0)
 
 // Per-launch extras of the GEMM launcher (gemm.hip: gemm_run) that the C ABI's cmp_k_gemm does not carry.  The model driver
 // fills one per call, so nothing about a launch lives in process-wide state.

@@ -652,7 +652,7 @@ extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gam
     if (dtype == CMP_BF16) { if (maxi == 1) LN_FWD(bf16_t, 1); else if (maxi == 2) LN_FWD(bf16_t, 2); else if (maxi <= 4) LN_FWD(bf16_t, 4); else LN_FWD(bf16_t, 8); }
     else { if (maxi == 1) LN_FWD(float, 1); else if (maxi == 2) LN_FWD(float, 2); else if (maxi <= 4) LN_FWD(float, 4); else LN_FWD(float, 8); }
 #undef LN_FWD
-    PROF_STOP(6, s, (double)rows * (2.0 * E * dtype_size(dtype) + 8.0));
+    PROF_STOP(6, s, (double)rows * (2.0 * E * dtype_size(dtype) + 8.0), (double)rows * (2.0 * E * dtype_size(dtype) + 8.0));
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -690,6 +690,7 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
     const int maxi = cdiv(E / vn, 64);
     DropCfg dcfg = make_drop(p_drop, seed, rng_stream);
     if (p_drop <= 0.f) dmask = nullptr;          // no mask: the consumer reads dx itself
+    PROF_START(8, s);
     const int want_cs = colsum != nullptr;
     // up to 256 workgroups (rows <= 2048) the per-workgroup partials go to the gradients by atomics from the kernel itself; beyond
     // that (and always in deterministic mode) they are folded by ln_param_reduce_kernel
@@ -706,6 +707,10 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
     KERNEL_CHECK();
     if (!direct)
         ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), deterministic ? 1 : std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);
+    {   // class 8: dy, x (+ resid) in, dx (+ the dropout-masked copy) out, mean / rstd
+        const double lb = (double)rows * ((3.0 + (resid ? 1.0 : 0.0) + (dmask ? 1.0 : 0.0)) * E * dtype_size(dtype) + 8.0);
+        PROF_STOP(8, s, lb, lb);
+    }
     KERNEL_CHECK();
     return CMP_OK;
 }
@@ -745,7 +750,7 @@ extern "C" int cmp_k_adam(void* stream, float* p, const float* g, float* m, floa
     int grid = (int)std::min<int64_t>(cdiv64(n4, 256), 8192);
     PROF_START(7, s);
     adam_kernel<<<grid, 256, 0, s>>>(p, g, m, v, (bf16_t*)shadow_bf16, n4, n, (float)alpha, beta1, beta2, eps, grad_scale);
-    PROF_STOP(7, s, (double)n * (28.0 + (shadow_bf16 ? 2.0 : 0.0)));
+    PROF_STOP(7, s, (double)n * (28.0 + (shadow_bf16 ? 2.0 : 0.0)), (double)n * (28.0 + (shadow_bf16 ? 2.0 : 0.0)));
     KERNEL_CHECK();
     return CMP_OK;
 }

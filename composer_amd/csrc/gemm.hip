@@ -1861,7 +1861,12 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
         else if (!ta && tb) gemm_bf16_kernel<true, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
         else if (ta && !tb) gemm_bf16_kernel<false, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
         else gemm_bf16_kernel<false, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per);
-        PROF_STOP(cls, s, 2.0 * M * N * K);
+        {   // algorithmic HBM bytes: A, B (+ bias, gelu' operand, residual) in; C (+ the stored pre-activation) out, once each
+            const double oe = out_fp32 ? 4.0 : 2.0;
+            const double gb = 2.0 * ((double)M * K + (double)K * N) + oe * M * N + (bias ? 4.0 * N : 0.0) + (aux ? 2.0 * M * N : 0.0) +
+                              (resid ? 2.0 * M * N : 0.0);
+            PROF_STOP(cls, s, 2.0 * M * N * K, gb);
+        }
     }
     {
         const hipError_t le = hipGetLastError();

@@ -131,6 +131,16 @@ struct cmp_model {
                                        // object remembers the pass it came from and cmp_present_get_at refuses any other
     std::vector<hipEvent_t> bucket_ev; // L+2 events
     hipEvent_t comm_done = nullptr, metrics_ev = nullptr;
+    // data-parallel telemetry (cmp_dp_stats): a ring of timed event pairs around the compute stream's wait for the
+    // communication stream at the end of a step = the communication time the backward pass did NOT hide
+    static constexpr int DP_RING = 32;
+    hipEvent_t dp_wait_a[DP_RING] = {}, dp_wait_b[DP_RING] = {};
+    bool dp_wait_used[DP_RING] = {};
+    int64_t dp_steps = 0;              // steps recorded since the last reset
+    int64_t dp_folded = 0;             // ... of which already summed into dp_exposed_ms
+    double dp_exposed_ms = 0.0;
+    int64_t dp_bytes_step = 0;         // bytes handed to ncclAllReduce by the last step (gradients + the 3-float metrics message)
+    int dp_msgs_step = 0;              // all-reduce calls of the last step
     DecodeState* dec = nullptr;
     int gemm_role = -1;                // profiler class of the GEMMs being enqueued (0 while the forward pass is)
 

@@ -38,7 +38,7 @@ extern "C" int cmp_device_count(void) {
 thread_local int g_prof_cls = -1;
 static thread_local std::vector<hipEvent_t> g_prof_ev;     // start/stop pairs
 static thread_local size_t g_prof_used = 0;
-static thread_local double g_prof_work = 0.0;
+static thread_local double g_prof_work = 0.0, g_prof_bytes = 0.0;
 void prof_start(int, hipStream_t s) {
     if (g_prof_used + 2 > g_prof_ev.size()) {
         for (int i = 0; i < 256; i++) {
@@ -49,19 +49,23 @@ void prof_start(int, hipStream_t s) {
     }
     (void)hipEventRecord(g_prof_ev[g_prof_used], s);
 }
-void prof_stop(int, hipStream_t s, double work) {
+void prof_stop(int, hipStream_t s, double work, double bytes) {
     if (g_prof_used + 2 > g_prof_ev.size()) return;
     (void)hipEventRecord(g_prof_ev[g_prof_used + 1], s);
     g_prof_used += 2;
     g_prof_work += work;
+    g_prof_bytes += bytes;
 }
 extern "C" int cmp_prof_begin(int cls) {
     g_prof_cls = cls;
     g_prof_used = 0;
     g_prof_work = 0.0;
+    g_prof_bytes = 0.0;
     return CMP_OK;
 }
-extern "C" int cmp_prof_end(double* total_ms, int64_t* launches, double* work) {
+extern "C" int cmp_prof_end2(double* total_ms, int64_t* launches, double* work, double* bytes);
+extern "C" int cmp_prof_end(double* total_ms, int64_t* launches, double* work) { return cmp_prof_end2(total_ms, launches, work, nullptr); }
+extern "C" int cmp_prof_end2(double* total_ms, int64_t* launches, double* work, double* bytes) {
     g_prof_cls = -1;
     if (g_prof_used >= 2) HIP_CHECK(hipEventSynchronize(g_prof_ev[g_prof_used - 1]));       // the last recorded stop event (same stream order)
     double t = 0.0;
@@ -73,6 +77,7 @@ extern "C" int cmp_prof_end(double* total_ms, int64_t* launches, double* work) {
     if (total_ms) *total_ms = t;
     if (launches) *launches = (int64_t)(g_prof_used / 2);
     if (work) *work = g_prof_work;
+    if (bytes) *bytes = g_prof_bytes;
     g_prof_used = 0;
     return CMP_OK;
 }
@@ -346,6 +351,10 @@ extern "C" int cmp_model_destroy(cmp_model* m) {
     for (auto& e : m->bucket_ev) hipEventDestroy(e);
     if (m->comm_done) hipEventDestroy(m->comm_done);
     if (m->metrics_ev) hipEventDestroy(m->metrics_ev);
+    for (int i = 0; i < cmp_model::DP_RING; i++) {
+        if (m->dp_wait_a[i]) hipEventDestroy(m->dp_wait_a[i]);
+        if (m->dp_wait_b[i]) hipEventDestroy(m->dp_wait_b[i]);
+    }
     delete m;
     (void)hipGetLastError();        // whatever a teardown call reported must not surface in this thread's next launch check
     return CMP_OK;
@@ -721,20 +730,34 @@ static int wgrad_splits(int K, int M, int N) {
     return std::min(s, std::max(1, K / 256));
 }
 
-// A gradient bucket is complete on the compute stream: all-reduce it on the communication stream behind an event.
+// Keras Adam on elements [begin, end) of the flat buffers (transformer.py:887,921); `step` = optimizer.iterations + 1
+static int adam_range(cmp_model* m, hipStream_t s, int64_t begin, int64_t end, float lr, int64_t step, float gscale) {
+    return cmp_k_adam(s, m->P + begin, m->G + begin, m->Am + begin, m->Av + begin, m->S ? (void*)(m->S + begin) : nullptr, end - begin, lr,
+                      0.9f, 0.999f, 1e-7f, step, gscale);
+}
+
+// A gradient bucket is complete on the compute stream: all-reduce it on the communication stream behind an event, and
+// apply Adam to that bucket's parameters right behind its all-reduce, still on the communication stream -- nothing the
+// compute stream enqueues after this point reads them (a block's parameters are last read by its own backward pass, the
+// tied embedding by the first GEMMs of the backward pass), so only the LAST bucket's all-reduce + update is left for the
+// end-of-step wait instead of every bucket's update.
 // Runs whenever a communicator exists, also with ONE rank (RCCL then copies in place): the 1-GPU tests and a 1-rank
 // launched bench execute exactly the event / side-stream / ncclAllReduce sequence of the 8-GPU job.
-static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end) {
+// lr < 0: gradients only (no update).
+static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end, float lr) {
     cmp_ctx* c = m->ctx;
     if (!c->comm) return CMP_OK;
     HIP_CHECK(hipEventRecord(m->bucket_ev[ev], c->stream));
     HIP_CHECK(hipStreamWaitEvent(c->comm_stream, m->bucket_ev[ev], 0));
     NCCL_CHECK(ncclAllReduce(m->G + begin, m->G + begin, (size_t)(end - begin), ncclFloat, ncclSum, c->comm, c->comm_stream));
+    m->dp_bytes_step += (end - begin) * 4;
+    m->dp_msgs_step += 1;
+    if (lr >= 0.f) CHECK_RC(adam_range(m, c->comm_stream, begin, end, lr, m->iterations + 1, 1.0f / (float)c->nranks));
     return CMP_OK;
 }
 
 // reverse mode of forward() (tf.GradientTape, transformer.py:916-920); formulas in SURVEY appendix A
-static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t step, bool allreduce) {
+static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t step, bool allreduce, float lr = -1.f) {
     Range range_("composer.backward");
     hipStream_t s = m->ctx->stream;
     const int E = m->E, Ea = m->Ea, M = B * T, dt = m->dtype, V = m->V;
@@ -752,7 +775,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                     m->G + m->off_lnf_g, m->G + m->off_lnf_b, M, m->dmask, m->G + m->lo[m->L - 1].pr_b, pr,
                     drop_stream(step, m->L - 1, 3)));
     bool dmo_ready = true;      // dmask / pr_b of the current layer already produced
-    if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total));
+    if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total, lr));
     for (int i = m->L - 1; i >= 0; i--) {
         const LayerOff& o = m->lo[i];
         LayerAct& a = m->act[i];
@@ -808,11 +831,11 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * Ea, m->dqkv, 3 * Ea, m->w(o.attn_w), 3 * Ea, m->dx, E, nullptr, 0, nullptr, 0, m->dr, E,
                           0, 1, 0.f, 0));
         }
-        if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end));
+        if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end, lr));
     }
     CHECK_RC(embed_bwd_run(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->drop_seed(),
                            drop_stream(step, 0, 0), m->slab ? V : 0, (float*)m->slab, (size_t)m->slab_bytes));
-    if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin));
+    if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin, lr));
     return CMP_OK;
 }
 
@@ -832,23 +855,63 @@ static int dp_metrics_begin(cmp_model* m) {
     HIP_CHECK(hipEventRecord(m->metrics_ev, c->stream));
     HIP_CHECK(hipStreamWaitEvent(c->comm_stream, m->metrics_ev, 0));
     NCCL_CHECK(ncclAllReduce(m->dp_metrics, m->dp_metrics, 3, ncclFloat, ncclSum, c->comm, c->comm_stream));
+    m->dp_bytes_step = 12;          // first message of the step: the gradient buckets add theirs (bucket_ready)
+    m->dp_msgs_step = 1;
+    return CMP_OK;
+}
+
+// sums the finished event pairs of the ring into dp_exposed_ms (all == false: only the slot about to be reused)
+static int dp_fold(cmp_model* m, int slot, bool all) {
+    for (int i = 0; i < cmp_model::DP_RING; i++) {
+        if (!(all || i == slot) || !m->dp_wait_used[i]) continue;
+        HIP_CHECK(hipEventSynchronize(m->dp_wait_b[i]));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, m->dp_wait_a[i], m->dp_wait_b[i]));
+        m->dp_exposed_ms += ms;
+        m->dp_folded += 1;
+        m->dp_wait_used[i] = false;
+    }
     return CMP_OK;
 }
 
 static int adam(cmp_model* m, float lr) {
     Range range_("composer.adam");
     cmp_ctx* c = m->ctx;
-    float gscale = 1.0f;
-    if (c->comm) {
-        HIP_CHECK(hipEventRecord(m->comm_done, c->comm_stream));
-        HIP_CHECK(hipStreamWaitEvent(c->stream, m->comm_done, 0));
-        gscale = 1.0f / (float)c->nranks;       // all-reduce summed: global-batch mean gradient
-        dp_metrics_unpack_kernel<<<1, 64, 0, c->stream>>>(m->metrics, m->dp_metrics);
-        KERNEL_CHECK();
-    }
     m->iterations += 1;
     m->param_version += 1;
-    return cmp_k_adam(c->stream, m->P, m->G, m->Am, m->Av, m->S, m->total, lr, 0.9f, 0.999f, 1e-7f, m->iterations, gscale);
+    if (c->comm) {
+        // every bucket was all-reduced AND updated on the communication stream (bucket_ready); the compute stream waits for the
+        // last of them here, between two timed events: what they measure is the communication (+ last update) that the
+        // backward pass did not hide -- SURVEY 8d "exposed comm time per step", read with cmp_dp_stats
+        const int slot = (int)(m->dp_steps % cmp_model::DP_RING);
+        CHECK_RC(dp_fold(m, slot, false));
+        if (!m->dp_wait_a[slot]) {
+            HIP_CHECK(hipEventCreate(&m->dp_wait_a[slot]));
+            HIP_CHECK(hipEventCreate(&m->dp_wait_b[slot]));
+        }
+        HIP_CHECK(hipEventRecord(m->comm_done, c->comm_stream));
+        HIP_CHECK(hipEventRecord(m->dp_wait_a[slot], c->stream));
+        HIP_CHECK(hipStreamWaitEvent(c->stream, m->comm_done, 0));
+        HIP_CHECK(hipEventRecord(m->dp_wait_b[slot], c->stream));
+        m->dp_wait_used[slot] = true;
+        m->dp_steps += 1;
+        dp_metrics_unpack_kernel<<<1, 64, 0, c->stream>>>(m->metrics, m->dp_metrics);
+        KERNEL_CHECK();
+        return CMP_OK;
+    }
+    return adam_range(m, c->stream, 0, m->total, lr, m->iterations, 1.0f);
+}
+
+extern "C" int cmp_dp_stats(cmp_model* m, int reset, int64_t* steps, double* exposed_ms, int64_t* bytes_per_step, int* msgs_per_step) {
+    CMP_REQUIRE(m, "dp_stats: null model");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(dp_fold(m, -1, true));
+    if (steps) *steps = m->dp_folded;
+    if (exposed_ms) *exposed_ms = m->dp_exposed_ms;
+    if (bytes_per_step) *bytes_per_step = m->ctx->comm ? m->dp_bytes_step : 0;
+    if (msgs_per_step) *msgs_per_step = m->ctx->comm ? m->dp_msgs_step : 0;
+    if (reset) { m->dp_steps = 0; m->dp_folded = 0; m->dp_exposed_ms = 0.0; }
+    return CMP_OK;
 }
 
 static int fetch_metrics(cmp_model* m) {
@@ -877,7 +940,8 @@ static int train_step_enqueue(cmp_model* m, const int32_t* x_dev, const int32_t*
     CHECK_RC(model_forward(m, x_dev, B, T, true, step));
     CHECK_RC(loss(m, y_dev, B * T, true));
     CHECK_RC(dp_metrics_begin(m));
-    CHECK_RC(backward(m, x_dev, B, T, step, true));
+    CMP_REQUIRE(lr >= 0.f, "train step: learning rate %g is negative", (double)lr);
+    CHECK_RC(backward(m, x_dev, B, T, step, true, lr));
     CHECK_RC(adam(m, lr));
     return CMP_OK;
 }

@@ -222,6 +222,15 @@ class Transformer:
         _lib.check(self._lib.cmp_dp_allreduce_test(self._ctx, a.ctypes.data_as(C.c_void_p), a.size), 'cmp_dp_allreduce_test')
         return a
 
+    def dp_stats(self, reset=False):
+        """Gradient-exchange telemetry since the last reset (cmp_dp_stats): steps, the communication time per step that the
+        backward pass did not hide (ms), bytes and all-reduce calls per step.  Zeros without a communicator."""
+        steps, ms, nbytes, msgs = C.c_int64(), C.c_double(), C.c_int64(), C.c_int()
+        _lib.check(self._lib.cmp_dp_stats(self._h, int(bool(reset)), C.byref(steps), C.byref(ms), C.byref(nbytes), C.byref(msgs)),
+                   'cmp_dp_stats')
+        return {"steps": steps.value, "exposed_ms": ms.value / steps.value if steps.value else 0.0,
+                "exposed_ms_total": ms.value, "bytes": nbytes.value, "buckets": msgs.value}
+
     @staticmethod
     def new_unique_id():
         buf = C.create_string_buffer(128)

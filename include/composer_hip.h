@@ -91,6 +91,13 @@ int cmp_dp_set_gemm_cus(cmp_ctx* ctx, int cus);
  * reference is single-device).  cmp_dp_init sets the rank of the communicator; this call overrides it (tests, or a
  * launcher that shards without RCCL).  Parameter initialisation does NOT depend on it: replicas start identical. */
 int cmp_dp_set_mask_rank(cmp_ctx* ctx, int rank);
+/* Telemetry of the overlapped gradient exchange ("report exposed (non-overlapped) comm time per step").  Inside a
+ * train step every gradient bucket is all-reduced and Adam-updated on the communication stream while the backward pass goes
+ * on; at the end of the step the compute stream waits for that stream between two timed HIP events.  This call returns, over
+ * the steps since the last reset: their count, the SUM of those waits in milliseconds (0 per step = everything was hidden
+ * behind the backward pass), and the last step's bytes and number of ncclAllReduce calls (L+2 gradient buckets + the 3-float
+ * metrics message).  All zeros without a communicator.  Synchronises with the steps it reports. */
+int cmp_dp_stats(cmp_model* m, int reset, int64_t* steps, double* exposed_ms, int64_t* bytes_per_step, int* msgs_per_step);
 
 /* ---- model: replaces models.Transformer(...) construction (cli.py:123-132) --------------------- */
 /* Accepted configurations (anything else: CMP_ERR_INVALID with the reason in cmp_last_error): any vocabulary size; embedding_size
@@ -174,6 +181,9 @@ int cmp_k_sample(void* stream, const float* logits, int V, float temperature, ui
  * (flops for 0-5, bytes for 6-7). */
 int cmp_prof_begin(int cls);
 int cmp_prof_end(double* total_ms, int64_t* launches, double* work);
+/* the same, and the summed ALGORITHMIC HBM bytes of those launches (every operand read once, every result written once):
+ * what bench.py's per-class `algorithmic_bytes` is, next to the PMC-measured `traffic`.  Class 8 = layernorm backward. */
+int cmp_prof_end2(double* total_ms, int64_t* launches, double* work, double* bytes);
 
 /* ---- kernel-level entry points (dev pointers; dtype = cmp_dtype of activations) ----------------
  * Used by tests/ and bench.py to check and time single kernels against the oracle/roofline. */
