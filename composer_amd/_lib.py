@@ -94,6 +94,10 @@ SIGNATURES = {
     "cmp_k_adam": (_i, [_P, _P, _P, _P, _P, _P, _i64, _f, _f, _f, _f, _i64, _f]),
 }
 
+# entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
+# timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
+_ADDED_LATER = {"cmp_dp_stats", "cmp_prof_end2"}
+
 _lib = None
 
 
@@ -108,6 +112,8 @@ def load():
             "(hipcc, gfx950).  composer_amd has no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if name in _ADDED_LATER and os.environ.get("COMPOSER_HIP_LIB") and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

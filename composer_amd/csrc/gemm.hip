@@ -907,7 +907,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         // bijective XCD remap over items: the items one XCD works on are consecutive (shared A row panel in its L2)
         const int q = nitems >> 3, r = nitems & 7, x = item & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
-        const int tile = lin / nsplit, sp = lin % nsplit;
+        // split-major: consecutive items (= one XCD's group) are the TILES of one K range, which share that range's A and B
+        // panels through the XCD's L2.  (Tile-major -- the splits of one tile side by side -- gave an XCD sixteen disjoint K
+        // ranges: no operand byte shared, 2.4x the algorithmic bytes at the L2's memory side in the wgrad launches,
+        // profiles/r4_01_hbm_traffic.json.)
+        const int sp = lin / ntiles, tile = lin - sp * ntiles;
         m0 = (tile / tiles_n) * H_BM;
         n0 = (tile % tiles_n) * H_BN;
         kt0 = sp * ktiles_per_split;
@@ -1259,7 +1263,11 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
     auto item_coords = [&](int item, int& m0, int& n0, int& kt0, int& kt1) {
         const int q = nitems >> 3, r = nitems & 7, x = item & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
-        const int tile = lin / nsplit, sp = lin % nsplit;
+        // split-major: consecutive items (= one XCD's group) are the TILES of one K range, which share that range's A and B
+        // panels through the XCD's L2.  (Tile-major -- the splits of one tile side by side -- gave an XCD sixteen disjoint K
+        // ranges: no operand byte shared, 2.4x the algorithmic bytes at the L2's memory side in the wgrad launches,
+        // profiles/r4_01_hbm_traffic.json.)
+        const int sp = lin / ntiles, tile = lin - sp * ntiles;
         m0 = (tile / tiles_n) * BM;
         n0 = (tile % tiles_n) * H_BN;
         kt0 = sp * ksteps_per_split;

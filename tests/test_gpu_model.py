@@ -198,6 +198,42 @@ def test_single_rank_communicator_does_not_change_the_step():
     m.close()
 
 
+def test_exposed_communication_telemetry():
+    """cmp_dp_stats (SURVEY 8d "exposed comm time per step"): with a 1-rank communicator the step takes the product's
+    data-parallel sequence (every bucket all-reduced and Adam-updated on the communication stream); the call reports the steps,
+    the bytes handed to RCCL (all gradients in fp32 + the 3-float metrics message), the message count (L+2 buckets + 1) and how
+    long the compute stream waited for the communication stream at the end of each step.  A kernel that holds the communication
+    stream for 20 ms before the step (cmp_dp_test_hog) must show up as exposed time; without it the wait is far smaller."""
+    from composer_amd.transformer import Transformer
+    from composer_amd import _lib
+    g, cfg, params = load_golden("gA")
+    V, E, H, L, W, T, B = cfg
+    m = make_model(cfg, params, "fp32")
+    assert m.dp_stats() == {"steps": 0, "exposed_ms": 0.0, "exposed_ms_total": 0.0, "bytes": 0, "buckets": 0}      # no communicator
+    m.init_data_parallel(0, 1, Transformer.new_unique_id())
+    for s in range(3):
+        loss, _ = m.train_step(g["x"][s], g["y"][s], float(g["lr"]))
+        assert abs(loss - g["losses"][s]) <= 1e-4 * abs(g["losses"][s])
+    st = m.dp_stats(reset=True)
+    nparam = sum(int(np.prod(m.parameter_shape(n))) for n in m.parameter_names)
+    assert st["steps"] == 3 and st["buckets"] == L + 3
+    assert nparam * 4 + 12 <= st["bytes"] <= (nparam + 8 * len(m.parameter_names)) * 4 + 12        # tensors are padded to 8 elements
+    assert 0.0 <= st["exposed_ms"] < 5.0
+    quiet = st["exposed_ms"]
+    assert m.dp_stats()["steps"] == 0
+    for s in range(3, 6):
+        _lib.check(_lib.load().cmp_dp_test_hog(m._ctx, 8, 20000), "cmp_dp_test_hog")              # 20 ms on the communication stream
+        m.train_step(g["x"][s], g["y"][s], float(g["lr"]))
+    st = m.dp_stats()
+    assert st["steps"] == 3 and st["exposed_ms"] > 10.0 and st["exposed_ms"] > 10 * quiet, (st, quiet)
+    # the telemetry ring is reused after 32 steps without losing a step
+    m.dp_stats(reset=True)
+    for s in range(40):
+        m.train_step(g["x"][s % 10], g["y"][s % 10], float(g["lr"]))
+    assert m.dp_stats()["steps"] == 40
+    m.close()
+
+
 def test_two_shard_gradient_mean_equals_global_batch_on_the_hip_path():
     """Data-parallel equivalence on the product kernels: the mean of the HIP gradients of rows [0,B) and
     [B,2B) -- what the RCCL sum + the 1/N scale in the Adam kernel produce -- equals the HIP gradient of the 2B global batch."""
