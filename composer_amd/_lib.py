@@ -83,6 +83,7 @@ SIGNATURES = {
     "cmp_k_layernorm_bwd_ws": (_i64, [_i, _i]),
     "cmp_k_layernorm_bwd_fused": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _P, _f, _u64, _u32]),
     "cmp_k_gemm": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _i, _i, _f, _u64, _u32, _i]),
+    "cmp_k_wgrad_group": (_i, [_P, _i, _P, _P, _P, _P, _P, _P, _P, _P, _i]),
     "cmp_gemm_set_workspace": (_i, [_P, _i64]),
     "cmp_gemm_colsum_next": (_i, [_P]),
     "cmp_gemm_set_stamps": (_i, [_P]),
@@ -96,7 +97,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_dp_stats", "cmp_prof_end2"}
+_ADDED_LATER = {"cmp_dp_stats", "cmp_prof_end2", "cmp_k_wgrad_group"}
 
 _lib = None
 

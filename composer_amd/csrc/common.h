@@ -73,6 +73,20 @@ struct GemmExtra {
     bool dp = false;             // the launch belongs to a data-parallel job: persistent kernels hand their items out dynamically
     SchedWs* sched = nullptr;    // the calling context's item-counter workspace (a cmp_ctx is single-threaded by contract: no lock)
 };
+// One launch for several split-K weight gradients that contract over the same K rows (gemm.hip: gemm_wgrad_group_kernel):
+// problem i is C_i[M_i, N_i] (fp32, accumulated into) += A_i^T . B_i with A_i stored [K, M_i] and B_i stored [K, N_i], bf16.
+struct WgradProblem { const void* A; int lda; const void* B; int ldb; float* C; int ldc; int M, N; };
+struct WgradGroup {              // owned by the caller, one per call site whose problems keep their pointers (a decoder block)
+    void* dev = nullptr;         // device copy of the problem descriptors + the item table
+    size_t dev_bytes = 0;
+    std::string key;             // what that copy was built from (problems, K, workgroup count)
+    std::string host;            // the bytes uploaded (kept until the next rebuild: the upload is stream-ordered)
+    int nitems = 0, grid = 0;    // nitems == 0 with a key: the cost model chose one launch per problem for these shapes
+    bool force = false;          // use the grouped launch even where the cost model prefers separate launches (kernel-level tests)
+};
+// returns CMP_OK with *handled = false when the shapes do not fit the grouped kernel (the caller then runs the problems one by one)
+int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int nprob, int K, const GemmExtra& ex, bool* handled);
+void wgrad_group_free(WgradGroup* g);
 int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* Bm, int ldb,
              void* C, int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
              int splitk, float p_drop, uint64_t seed, uint32_t rng_stream, int flags, const GemmExtra& ex);

@@ -1236,13 +1236,25 @@ __device__ __forceinline__ bf16x8 p_frag(const char* img, int t16, int lane) {
     }
 }
 
+// ---- grouped weight gradients: ONE launch for several split-K problems that contract over the same K (the four Conv1D
+// weight gradients of a decoder block contract over the tokens).  Every launch of a split-K problem pays for 256 partial
+// 256x256 f32 tiles going through the memory-side float-atomic unit (64 MB at ~1.3 TB/s = ~50 us, MI355X_MICROARCH "Global float
+// atomics": measured as the K-independent part of a wgrad launch, 232 us at K = 131072 against 97 us at K = 32768), whatever its
+// depth.  Grouped, the block's 48 output tiles (C2) are cut stream-K fashion into one contiguous (tile, k-range) segment per
+// workgroup -- a segment that crosses a tile boundary becomes two items -- so the block pays for ~300 partial tiles once instead of
+// 4 x 256, every workgroup contracts the same number of k-steps, and the workgroups of an XCD are given segments of the same K
+// octant (its L2 fetches each operand panel once).  The host builds the item table (gemm_wgrad_group_run).
+#define WG_MAXP 8
+struct WgProb { const bf16_t* A; const bf16_t* B; float* C; int M, N, lda, ldb, ldc, pad; };      // 48 bytes, in device memory
+// item table entry: {problem, m0 | n0 << 16, first k-step, end k-step}; first == end: nothing to do
+
 // NWM: wave rows (1: 128x256 tile, 4 waves, 2 workgroups per CU; 2: 256x256 tile, 8 waves, 1 per CU).  NST: LDS stages.
-template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST, bool DIAG = false, int EPI = EPI_GENERIC>
-__global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
-                                                                    const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
-                                                                    Epilogue ep, int ksteps_per_split, int nsplit, int tiles_n,
-                                                                    int ntiles, int64_t slab_stride,
-                                                                    unsigned long long* stamps) {
+template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST, bool DIAG, int EPI, bool GROUPED>
+__device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
+                                        const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
+                                        const Epilogue& ep, int ksteps_per_split, int nsplit, int tiles_n,
+                                        int ntiles, int64_t slab_stride,
+                                        unsigned long long* stamps, const WgProb* __restrict__ gprobs, const int4* __restrict__ gitems) {
     // DIAG instantiation only (tools/gemm_timeline.py): workgroup 17, wave 0 records s_memtime at fixed points of its
     // first items into a buffer nothing else reads.  The product instantiation compiles the stamps away.
     constexpr int BM = 128 * NWM;
@@ -1256,11 +1268,21 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int nitems = ntiles * nsplit;
+    const int nitems = GROUPED ? ntiles : ntiles * nsplit;          // grouped: `ntiles` carries the length of the item table
     const int nk = cdiv(K, P_BK);
 
     int cur_split = 0;
     auto item_coords = [&](int item, int& m0, int& n0, int& kt0, int& kt1) {
+        if constexpr (GROUPED) {
+            const int4 d = gitems[item];                  // wave-uniform index: scalar loads
+            const WgProb pr = gprobs[d.x];
+            A = pr.A; B = pr.B; C = pr.C; M = pr.M; N = pr.N; lda = pr.lda; ldb = pr.ldb; ldc = pr.ldc;
+            m0 = d.y & 0xFFFF;
+            n0 = (int)((unsigned)d.y >> 16);
+            kt0 = d.z;
+            kt1 = d.w;
+            return;
+        }
         const int q = nitems >> 3, r = nitems & 7, x = item & 7;
         const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
         // split-major: consecutive items (= one XCD's group) are the TILES of one K range, which share that range's A and B
@@ -1349,6 +1371,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         run = __builtin_amdgcn_readfirstlane(slot[1]) == 0;
         if (!run) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the speculative stages have landed: their buffers may be refilled
     }
+    if (GROUPED && kt1 <= kt0) run = false;                // an empty table entry: no k-loop, no epilogue
     while (true) {
         f32x4 acc[8][4];
 #pragma unroll
@@ -1446,6 +1469,8 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         __builtin_amdgcn_s_barrier();          // every wave has finished reading the stages of this item
         stamp(21);
         const int cm0 = m0, cn0 = n0;
+        void* const Ccur = C;                  // (grouped: item_coords() below moves C / M / N / ldc on to the NEXT item's problem)
+        const int Mcur = M, Ncur = N, ldccur = ldc;
         // split-K with a slab workspace: every split writes its own fp32 partial tile with the ordinary full-line
         // epilogue (plain stores run ~4-5x the f32-atomic rate and the sum is reproducible); gemm_slab_reduce folds them
         void* Cit = slab_stride ? (void*)((float*)C + (int64_t)cur_split * slab_stride) : C;
@@ -1503,18 +1528,18 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             }
             }
         } else {
-            float* Cf = (float*)C;
+            float* Cf = (float*)Ccur;
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int col = cn0 + wn * 64 + j * 16 + (lane & 15);
                     const int row0 = cm0 + wm * 128 + i * 16 + (lane >> 4) * 4;
-                    if (col < N) {
-                        if (row0 + 0 < M) atomicAdd(Cf + (int64_t)(row0 + 0) * ldc + col, acc[i][j][0]);
-                        if (row0 + 1 < M) atomicAdd(Cf + (int64_t)(row0 + 1) * ldc + col, acc[i][j][1]);
-                        if (row0 + 2 < M) atomicAdd(Cf + (int64_t)(row0 + 2) * ldc + col, acc[i][j][2]);
-                        if (row0 + 3 < M) atomicAdd(Cf + (int64_t)(row0 + 3) * ldc + col, acc[i][j][3]);
+                    if (col < Ncur) {
+                        if (row0 + 0 < Mcur) atomicAdd(Cf + (int64_t)(row0 + 0) * ldccur + col, acc[i][j][0]);
+                        if (row0 + 1 < Mcur) atomicAdd(Cf + (int64_t)(row0 + 1) * ldccur + col, acc[i][j][1]);
+                        if (row0 + 2 < Mcur) atomicAdd(Cf + (int64_t)(row0 + 2) * ldccur + col, acc[i][j][2]);
+                        if (row0 + 3 < Mcur) atomicAdd(Cf + (int64_t)(row0 + 3) * ldccur + col, acc[i][j][3]);
                     }
                 }
         }
@@ -1541,7 +1566,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
             for (int i = 0; i < AHEAD; i++)
                 if (kt0 + i < kt1) issue(kt0 + i, i);
         }
-        run = true;
+        run = !(GROUPED && kt1 <= kt0);
         if (pl.ctr && tid == 0) slot[2] = (int)pend2;       // parked before the next item's k-loop
         item = next;
         // the epilogue's stores/atomics sit in the same vmcnt queue behind the prefetched stages: drain them so the
@@ -1551,6 +1576,22 @@ __global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         stamp(31);
     }
+}
+
+template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST, bool DIAG = false, int EPI = EPI_GENERIC>
+__global__ __launch_bounds__(256 * NWM, 2) void gemm_bf16_p4_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
+                                                                    const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
+                                                                    Epilogue ep, int ksteps_per_split, int nsplit, int tiles_n,
+                                                                    int ntiles, int64_t slab_stride,
+                                                                    unsigned long long* stamps) {
+    p4_body<A_KM, B_KM, SWAP, NWM, NST, DIAG, EPI, false>(M, N, K, A, lda, B, ldb, C, ldc, ep, ksteps_per_split, nsplit, tiles_n, ntiles,
+                                                          slab_stride, stamps, nullptr, nullptr);
+}
+// the grouped launch: operands stored [K, M_p] / [K, N_p] (contraction over rows), f32 atomics into C_p; nitems table entries
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_group_kernel(int K, const WgProb* __restrict__ gprobs, const int4* __restrict__ gitems,
+                                                                  int nitems, Epilogue ep) {
+    p4_body<false, false, false, 2, 4, false, EPI_GENERIC, true>(0, 0, K, nullptr, 0, nullptr, 0, nullptr, 0, ep, 0, 1, 1, nitems, (int64_t)0,
+                                                                 nullptr, gprobs, gitems);
 }
 
 // dynamic-LDS opt-in, once per kernel
@@ -1732,6 +1773,132 @@ static int sched_next(hipStream_t s, Epilogue& ep, const GemmExtra& ex, std::uni
 }
 void sched_ws_free(SchedWs* w) {
     if (w && w->dev) { (void)hipFree(w->dev); w->dev = nullptr; }
+}
+
+// ---- grouped weight gradients: the item table ---------------------------------------------------------------------------
+// All T output tiles (of all problems) are cut into the SAME s = floor(G / T) K ranges; item lin = range * T + tile, dealt to the
+// XCD groups in consecutive runs like every persistent launch here: the workgroups of an XCD contract the same rows of
+// different tiles in step, so its L2 fetches each operand panel once.  (A stream-K cut -- one contiguous range of exactly
+// T * nk / G k-steps per workgroup -- was built first and measured: every workgroup equally long, but the ranges of an XCD start
+// at unrelated rows, nothing is shared through L2, and the launch took 890 us at K = 131072 where this form is predicted at
+// ~800 and four split-K launches take 902-954; at C4's 108 tiles it lost 3.6 % of the step.)
+// Cost model in k-steps of 32 (tools/kbench.py wgradgroup: 0.91 us per k-step, 54 us = 59 k-steps of atomic epilogue per launch):
+// grouped = ceil(nk / s) * rounds + 59 against the sum over problems of nk / split_p + 59 -- the grouped launch is used when it wins.
+void wgrad_group_free(WgradGroup* g) {
+    if (g && g->dev) { (void)hipFree(g->dev); g->dev = nullptr; g->dev_bytes = 0; g->key.clear(); }
+}
+int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int nprob, int K, const GemmExtra& ex, bool* handled) {
+    *handled = false;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = (ex.max_wgs > 0 ? std::min(ex.max_wgs, 256) : 256) & ~7;
+    if (nprob < 1 || nprob > WG_MAXP || K < P_BK || K % P_BK != 0 || G < 8 || ex.slab_ws) return CMP_OK;
+    for (int i = 0; i < nprob; i++) {
+        const WgradProblem& q = probs[i];
+        if (q.M <= 0 || q.N <= 0 || q.M >= 65536 - 256 || q.N >= 65536 - 256 || q.lda % 8 || q.ldb % 8 || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15) ||
+            (int64_t)K * q.lda * 2 >= 0x7FFFFFF0ll || (int64_t)K * q.ldb * 2 >= 0x7FFFFFF0ll)
+            return CMP_OK;
+    }
+    std::string key((const char*)probs, sizeof(WgradProblem) * nprob);
+    key.append((const char*)&K, sizeof(K));
+    key.append((const char*)&G, sizeof(G));
+    if (key != g->key) {
+        struct Seg { int prob, m0, n0; };
+        std::vector<Seg> tiles;
+        for (int i = 0; i < nprob; i++)
+            for (int tm = 0; tm < cdiv(probs[i].M, 256); tm++)
+                for (int tn = 0; tn < cdiv(probs[i].N, 256); tn++) tiles.push_back({i, tm * 256, tn * 256});
+        const int T = (int)tiles.size(), nk = K / P_BK;
+        const int sp = std::max(1, std::min(G / T, nk)), chunk = cdiv(nk, sp), nsp = cdiv(nk, chunk);
+        const int nitems = T * nsp;
+        {   // is one grouped launch cheaper than one split-K launch per problem?  (model above; K-independent overhead in k-steps)
+            const double ov = 59.0;
+            const double grouped = (double)chunk * cdiv(nitems, G) + ov;
+            double separate = 0.0;
+            for (int i = 0; i < nprob; i++) {
+                const int t = cdiv(probs[i].M, 256) * cdiv(probs[i].N, 256);
+                const int si = std::max(1, std::min(G / std::max(1, t), nk));
+                separate += (double)cdiv(nk, si) * cdiv(t * si, G) + ov;
+            }
+            if (grouped >= separate && !g->force) {      // remembered: the next call with these shapes returns at once
+                g->key = key;
+                g->nitems = 0;
+                return CMP_OK;
+            }
+        }
+        std::string host(WG_MAXP * sizeof(WgProb) + (size_t)nitems * sizeof(int4), '\0');
+        WgProb* hp = (WgProb*)&host[0];
+        for (int i = 0; i < nprob; i++)
+            hp[i] = WgProb{(const bf16_t*)probs[i].A, (const bf16_t*)probs[i].B, probs[i].C, probs[i].M, probs[i].N, probs[i].lda, probs[i].ldb,
+                           probs[i].ldc, 0};
+        int4* hi = (int4*)&host[WG_MAXP * sizeof(WgProb)];
+        const int q = nitems >> 3, r = nitems & 7;
+        for (int item = 0; item < nitems; item++) {
+            const int x = item & 7;                                        // the XCD group of the item (ItemPuller): consecutive lin per group
+            const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
+            const int j = lin / T, t = lin - j * T;
+            hi[item] = make_int4(tiles[t].prob, tiles[t].m0 | (tiles[t].n0 << 16), j * chunk, std::min(nk, (j + 1) * chunk));
+        }
+        HIP_CHECK(hipStreamSynchronize(s));            // the previous table of this group may still be in use / in flight (a rebuild is rare)
+        if (g->dev_bytes < host.size()) {
+            wgrad_group_free(g);
+            HIP_CHECK(hipMalloc(&g->dev, host.size()));
+            g->dev_bytes = host.size();
+        }
+        g->host.swap(host);
+        HIP_CHECK(hipMemcpyAsync(g->dev, g->host.data(), g->host.size(), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        g->key = key;
+        g->nitems = nitems;
+        g->grid = std::min(nitems, G);
+    }
+    if (g->nitems == 0) return CMP_OK;                 // the cost model chose one launch per problem for these shapes
+    Epilogue ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.atomic = 1;
+    ep.out_fp32 = 1;
+    ep.drop = make_drop(0.f, 0, 0);
+    std::unique_lock<std::mutex> sched_lock;
+    SchedWs* sched_used = nullptr;
+    CHECK_SCHED(sched_next(s, ep, ex, sched_lock, &sched_used));
+    static bool attr_set = false;
+    const size_t smem = (size_t)4 * (256 * P_BK * 2 + 256 * P_BK * 2) + 16;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < nprob; i++) {
+        flops += 2.0 * probs[i].M * probs[i].N * K;
+        bytes += 2.0 * ((double)probs[i].M * K + (double)K * probs[i].N) + 4.0 * probs[i].M * probs[i].N;
+    }
+    PROF_START(2, s);
+    gemm_wgrad_group_kernel<<<g->grid, 512, smem, s>>>(K, (const WgProb*)g->dev, (const int4*)((const char*)g->dev + WG_MAXP * sizeof(WgProb)),
+                                                        g->nitems, ep);
+    PROF_STOP(2, s, flops, bytes);
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            if (sched_used) sched_used->dirty = true;
+            cmp_set_error("%s:%d: grouped wgrad launch failed: %s", __FILE__, __LINE__, hipGetErrorString(le));
+            return CMP_ERR_HIP;
+        }
+    }
+    *handled = true;
+    return CMP_OK;
+}
+// kernel-level entry point of the grouped launch (tests, micro-benchmarks): nprob problems given as parallel arrays
+extern "C" int cmp_k_wgrad_group(void* stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                 float* const* C, const int* ldc, const int* M, const int* N, int K) {
+    CMP_REQUIRE(nprob >= 1 && nprob <= WG_MAXP && A && B && C && lda && ldb && ldc && M && N, "wgrad_group: bad arguments");
+    static thread_local WgradGroup grp;           // rebuilt whenever the problems change
+    grp.force = true;                             // this entry point IS the grouped launch, whatever the cost model says
+    WgradProblem pr[WG_MAXP];
+    for (int i = 0; i < nprob; i++) pr[i] = WgradProblem{A[i], lda[i], B[i], ldb[i], C[i], ldc[i], M[i], N[i]};
+    GemmExtra ex;
+    bool handled = false;
+    CHECK_SCHED(wgrad_group_run(stream, &grp, pr, nprob, K, ex, &handled));
+    CMP_REQUIRE(handled, "wgrad_group: these shapes do not fit the grouped kernel (K %% 32, leading dimensions %% 8, 16-byte alignment, < 2 GiB operands)");
+    return CMP_OK;
 }
 
 extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda,

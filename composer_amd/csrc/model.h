@@ -109,6 +109,8 @@ struct cmp_model {
     float *logits = nullptr, *lnf_mean = nullptr, *lnf_rstd = nullptr, *row_loss = nullptr, *delta = nullptr;
     int32_t *row_correct = nullptr, *x_dev = nullptr, *y_dev = nullptr;
     void *dx = nullptr, *dr = nullptr, *tmpE = nullptr, *dmask = nullptr, *dfc = nullptr, *dqkv = nullptr;
+    void* dmask2 = nullptr;            // the attention branch's masked gradient: both masked copies of a block stay live until its grouped wgrad launch
+    std::vector<WgradGroup> wgrad_groups;      // per decoder block: item table + problem descriptors of that launch
     void* ln_ws = nullptr;
     void* slab = nullptr;              // split-K slab workspace (deterministic mode only)
     int64_t slab_bytes = 0;

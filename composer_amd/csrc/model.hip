@@ -341,6 +341,7 @@ extern "C" int cmp_model_destroy(cmp_model* m) {
     if (m->ctx->copy_stream) hipStreamSynchronize(m->ctx->copy_stream);
     if (m->dec) decode_state_free(m->dec);
     for (void* p : m->allocs) hipFree(p);
+    for (auto& wg : m->wgrad_groups) wgrad_group_free(&wg);
     if (m->metrics_host) hipHostFree(m->metrics_host);
     if (m->stage_metrics) hipHostFree(m->stage_metrics);
     for (int i = 0; i < cmp_model::STAGES; i++) {
@@ -530,6 +531,7 @@ static int ensure_workspace_fill(cmp_model* m, int B, int T) {
     CHECK_RC(dev_alloc(m, &m->dr, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->tmpE, (size_t)M * m->Ea * es));          // [M, E] gradients and the [M, Ea] attention-output gradient
     CHECK_RC(dev_alloc(m, &m->dmask, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->dmask2, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->dfc, (size_t)M * 4 * E * es));
     CHECK_RC(dev_alloc(m, &m->dqkv, (size_t)M * 3 * m->Ea * es));
     {   // COMPOSER_DETERMINISTIC=1: no float atomics anywhere in the step -- split-K wgrads write per-split slabs and fold them
@@ -776,27 +778,40 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                     drop_stream(step, m->L - 1, 3)));
     bool dmo_ready = true;      // dmask / pr_b of the current layer already produced
     if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total, lr));
+    // The four Conv1D weight gradients of a block contract over the same M tokens: with LayerNorm, bf16 and the atomic
+    // (non-deterministic) split-K form they go out as ONE grouped launch behind the block's attention backward (gemm.hip:
+    // gemm_wgrad_group_kernel) -- a quarter of the f32-atomic traffic of four split-K launches, equal k-steps per workgroup.
+    // Until then both masked gradient copies of the block stay live: the MLP branch's in dmask, the attention branch's in dmask2.
+#ifdef COMPOSER_WGRAD_UNGROUPED
+    const bool grouped = false;
+#else
+    const bool grouped = ln && dt == CMP_BF16 && !m->slab;
+#endif
+    if (grouped && (int)m->wgrad_groups.size() != m->L) m->wgrad_groups.resize(m->L);
     for (int i = m->L - 1; i >= 0; i--) {
         const LayerOff& o = m->lo[i];
         LayerAct& a = m->act[i];
+        bool group_now = grouped;
         // ---- MLP: x_out = r + dropout(gelu(n.Wfc+b).Wpr+b)
         const void* dmo = m->dx;
         if (pr > 0.f) {
             if (!dmo_ready) CHECK_RC(drop_apply(m, m->dx, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 3)));
             dmo = m->dmask;
         }
-        CHECK_RC(gemm(m, 1, 0, 4 * E, E, M, a.g, 4 * E, dmo, E, m->G + o.pr_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
-                      std::max(2, wgrad_splits(M, 4 * E, E)), 0.f, 0));
+        auto wgrad = [&](int Mw, int Nw, const void* A, int lda, const void* Bm, int ldb, float* Cw) {
+            return gemm(m, 1, 0, Mw, Nw, M, A, lda, Bm, ldb, Cw, Nw, nullptr, 0, nullptr, 0, nullptr, 0, 1, std::max(2, wgrad_splits(M, Mw, Nw)), 0.f, 0);
+        };
+        if (!group_now) CHECK_RC(wgrad(4 * E, E, a.g, 4 * E, dmo, E, m->G + o.pr_w));
         if (!dmo_ready) CHECK_RC(colsum_any(m, dmo, E, m->G + o.pr_b, M, E));
         CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, dmo, E, m->w(o.pr_w), E, m->dfc, 4 * E, nullptr, 2, a.fc, 4 * E, nullptr, 0, 0, 1,
                       0.f, 0, 0, m->G + o.fc_b));      // dfc = (dmo.Wpr^T) * gelu'(fc); b_fc grad = column sums of dfc
-        CHECK_RC(gemm(m, 1, 0, E, 4 * E, M, a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
-                      std::max(2, wgrad_splits(M, E, 4 * E)), 0.f, 0));
+        if (!group_now) CHECK_RC(wgrad(E, 4 * E, a.n, E, m->dfc, 4 * E, m->G + o.fc_w));
+        void* const dao_mask = group_now ? m->dmask2 : m->dmask;
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr,
                           0, 0, 1, 0.f, 0));                                       // dn
             CHECK_RC(ln_bwd(m, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr, m->G + o.ln2_g, m->G + o.ln2_b, M,
-                            m->dmask, m->G + o.proj_b, pr, drop_stream(step, i, 2)));   // dr = dx + LN2'(dn); dao, b_proj grad
+                            dao_mask, m->G + o.proj_b, pr, drop_stream(step, i, 2)));   // dr = dx + LN2'(dn); dao, b_proj grad
         } else {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->dr, E, nullptr, 0, nullptr, 0, m->dx, E,
                           0, 1, 0.f, 0));                                          // dr = dx + dn
@@ -805,10 +820,9 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         const void* dao = m->dr;
         if (pr > 0.f) {
             if (!ln) CHECK_RC(drop_apply(m, m->dr, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 2)));
-            dao = m->dmask;
+            dao = dao_mask;
         }
-        CHECK_RC(gemm(m, 1, 0, Ea, E, M, a.att, Ea, dao, E, m->G + o.proj_w, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
-                      std::max(2, wgrad_splits(M, Ea, E)), 0.f, 0));
+        if (!group_now) CHECK_RC(wgrad(Ea, E, a.att, Ea, dao, E, m->G + o.proj_w));
         if (!ln) CHECK_RC(colsum_any(m, dao, E, m->G + o.proj_b, M, E));
         CHECK_RC(gemm(m, 0, 1, M, Ea, E, dao, E, m->w(o.proj_w), E, m->tmpE, Ea, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
                       0));                                                         // datt
@@ -816,8 +830,28 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, attn_scale(m),
                               dt, pa, m->drop_seed(), drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b));   // b_attn grad = column sums of dqkv
         if (det) CHECK_RC(colsum_det(m, m->dqkv, 3 * Ea, m->G + o.attn_b, M, 3 * Ea));
-        CHECK_RC(gemm(m, 1, 0, E, 3 * Ea, M, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w, 3 * Ea, nullptr, 0, nullptr, 0, nullptr, 0,
-                      1, std::max(2, wgrad_splits(M, E, 3 * Ea)), 0.f, 0));
+        if (group_now) {
+            const WgradProblem wp[4] = {
+                {a.g, 4 * E, dmo, E, m->G + o.pr_w, E, 4 * E, E},                  // dWpr   = g^T . dmo
+                {a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, E, 4 * E},           // dWfc   = n^T . dfc
+                {a.att, Ea, dao, E, m->G + o.proj_w, E, Ea, E},                    // dWproj = att^T . dao
+                {a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w, 3 * Ea, E, 3 * Ea}};    // dWattn = u^T . dqkv
+            GemmExtra ex;
+            ex.role = 2;
+            ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;
+            ex.dp = m->ctx->comm != nullptr;
+            ex.sched = &m->ctx->gemm_sched;
+            bool handled = false;
+            CHECK_RC(wgrad_group_run(s, &m->wgrad_groups[i], wp, 4, M, ex, &handled));
+            if (!handled) {          // shapes outside the grouped kernel's domain (M % 32, ...): one launch each, as without grouping
+                CHECK_RC(wgrad(4 * E, E, a.g, 4 * E, dmo, E, m->G + o.pr_w));
+                CHECK_RC(wgrad(E, 4 * E, a.n, E, m->dfc, 4 * E, m->G + o.fc_w));
+                CHECK_RC(wgrad(Ea, E, a.att, Ea, dao, E, m->G + o.proj_w));
+                CHECK_RC(wgrad(E, 3 * Ea, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w));
+            }
+        } else {
+            CHECK_RC(wgrad(E, 3 * Ea, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w));
+        }
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * Ea, m->dqkv, 3 * Ea, m->w(o.attn_w), 3 * Ea, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
                           E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T

@@ -222,6 +222,13 @@ int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
 #define CMP_GEMM_TILE256 8      /* tests/bench: force the persistent 256x256 2-stage kernel */
 #define CMP_GEMM_P4 16          /* tests/bench: force the persistent deep-pipeline (BK=32) kernel */
 #define CMP_GEMM_P4_128 32      /* with CMP_GEMM_P4: 128x256 tile / 4 waves / 3 stages / 2 workgroups per CU instead of 256x256 / 8 waves / 4 stages */
+/* ONE launch for up to 8 split-K weight gradients that contract over the same K rows -- the four Conv1D weight gradients of a
+ * decoder block (tf.GradientTape through transformer.py:205-209) contract over the tokens: C_i[M_i, N_i] (fp32, ACCUMULATED into
+ * with f32 atomics) += A_i^T . B_i, A_i bf16 stored [K, M_i] (lda_i), B_i bf16 stored [K, N_i] (ldb_i).  Requirements
+ * (CMP_ERR_INVALID otherwise): K a multiple of 32, leading dimensions multiples of 8, 16-byte aligned operands, every operand
+ * below 2 GiB.  The model's backward pass uses this launch in bf16 mode. */
+int cmp_k_wgrad_group(void* stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                      float* const* C, const int* ldc, const int* M, const int* N, int K);
 /* Registers a device workspace for split-K reductions: with it, split-K launches write per-split fp32 partial tiles and
  * fold them in a fixed order (reproducible, no float atomics); without it (or if too small: splitk*M*N*4 bytes) they
  * accumulate with f32 atomics.  flags & 128 forces the atomic path. */

@@ -89,6 +89,53 @@ def test_gemm_layouts(lib, dtype, ta, tb, M, N, K, flags):
     assert rel_err(out, ref) < TOL[dtype]
 
 
+def wgrad_group(lib, As, Bs, Cs, K):
+    n = len(As)
+    vp, ip = C.c_void_p * n, C.c_int * n
+    ck(lib, lib.cmp_k_wgrad_group(stream(), n, vp(*[a.data_ptr() for a in As]), ip(*[a.shape[1] for a in As]),
+                                  vp(*[b.data_ptr() for b in Bs]), ip(*[b.shape[1] for b in Bs]), vp(*[c.data_ptr() for c in Cs]),
+                                  ip(*[c.shape[1] for c in Cs]), ip(*[a.shape[1] for a in As]), ip(*[b.shape[1] for b in Bs]), K))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("K", [32, 96, 2048, 8192 + 32])
+@pytest.mark.parametrize("shapes", [[(512, 2048), (2048, 512), (512, 512), (512, 1536)],           # a C2 decoder block
+                                    [(768, 3072), (3072, 768), (768, 768), (768, 2304)],           # a C4 decoder block
+                                    [(64, 64)], [(264, 520), (8, 8), (1000, 136)],                 # ragged tiles, one problem, tiny problems
+                                    [(256, 256)] * 8])
+def test_grouped_weight_gradients(lib, K, shapes):
+    """cmp_k_wgrad_group: C_i += A_i^T . B_i for all problems in ONE launch (stream-K items over all output tiles, f32 atomics)
+    against float64 products; C_i starts non-zero (accumulate semantics) and the bytes next to every C_i stay untouched."""
+    g = torch.Generator().manual_seed(K + len(shapes))
+    As = [torch.randn(K, m, generator=g).to(torch.bfloat16).cuda() for m, n in shapes]
+    Bs = [torch.randn(K, n, generator=g).to(torch.bfloat16).cuda() for m, n in shapes]
+    C0 = [torch.randn(m + 1, n, generator=g) for m, n in shapes]                  # one guard row behind each C_i
+    Cs = [c.clone().cuda() for c in C0]
+    wgrad_group(lib, As, Bs, [c[:-1] for c in Cs], K)
+    for a, b, c0, c in zip(As, Bs, C0, Cs):
+        ref = c0[:-1].double() + a.double().cpu().T @ b.double().cpu()
+        assert rel_err(c[:-1], ref) < 2e-5, (a.shape, b.shape)
+        assert torch.equal(c[-1].cpu(), c0[-1])
+    # the same call again adds the products once more (and reuses the cached item table)
+    wgrad_group(lib, As, Bs, [c[:-1] for c in Cs], K)
+    for a, b, c0, c in zip(As, Bs, C0, Cs):
+        assert rel_err(c[:-1], c0[:-1].double() + 2 * (a.double().cpu().T @ b.double().cpu())) < 4e-5
+
+
+def test_grouped_weight_gradients_at_the_timed_depth(lib):
+    """The C2 block at K = 131 072 tokens (bench.py's geometry): every problem against its float64 product."""
+    K = 131072
+    shapes = [(2048, 512), (512, 2048), (512, 512), (512, 1536)]
+    g = torch.Generator().manual_seed(9)
+    As = [torch.randn(K, m, generator=g).to(torch.bfloat16) for m, n in shapes]
+    Bs = [torch.randn(K, n, generator=g).to(torch.bfloat16) for m, n in shapes]
+    Cs = [torch.zeros(m, n, device="cuda") for m, n in shapes]
+    wgrad_group(lib, [a.cuda() for a in As], [b.cuda() for b in Bs], Cs, K)
+    for a, b, c in zip(As, Bs, Cs):
+        ref = torch.from_numpy(a.double().numpy().T @ b.double().numpy())
+        assert rel_err(c, ref) < 5e-5, (a.shape, b.shape)
+
+
 def test_gemm_bf16_ragged_k_zero_padded(lib):
     """dH = dZ.wte: K = V = 390 with dZ rows zero-padded to 448 (CMP_GEMM_KPAD_ZERO) takes the fast path."""
     M, N, K, ld = 300, 128, 390, 448

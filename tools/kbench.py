@@ -113,6 +113,33 @@ def bench_gemm():
     print("sum of the 12 per-layer GEMMs: %.1f us  (%.1f TFLOP/s average)" % (tot, 3 * 2.0 * M * 12 * E * E / tot / 1e6))
 
 
+def bench_wgrad_group():
+    """the four weight gradients of a decoder block: four split-K launches (model.hip::wgrad_splits) against ONE grouped launch"""
+    shapes = [(4 * E, E), (E, 4 * E), (E, E), (E, 3 * E)]
+    As = [rnd(M, m) for m, n in shapes]
+    Bs = [rnd(M, n) for m, n in shapes]
+    Cs = [torch.zeros(m, n, device="cuda") for m, n in shapes]
+    def four():
+        for (m, n), a, b, c in zip(shapes, As, Bs, Cs):
+            t256 = ((m + 255) // 256) * ((n + 255) // 256)
+            t128 = ((m + 127) // 128) * ((n + 127) // 128)
+            sk = max(1, 256 // t256) if t256 >= 8 else max(1, 768 // t128)
+            sk = max(2, min(sk, M // 256))
+            rc = lib.cmp_k_gemm(st(), BF16, 1, 0, m, n, M, P(a), m, P(b), n, P(c), n, None, 0, None, 0, None, 0, 1, sk, 0.0, 0, 0, GFLAGS)
+            assert rc == 0, lib.cmp_last_error()
+    n = len(shapes)
+    vp, ip = C.c_void_p * n, C.c_int * n
+    args = (vp(*[a.data_ptr() for a in As]), ip(*[m for m, _ in shapes]), vp(*[b.data_ptr() for b in Bs]), ip(*[k for _, k in shapes]),
+            vp(*[c.data_ptr() for c in Cs]), ip(*[k for _, k in shapes]), ip(*[m for m, _ in shapes]), ip(*[k for _, k in shapes]))
+    def one():
+        rc = lib.cmp_k_wgrad_group(st(), n, *args, M)
+        assert rc == 0, lib.cmp_last_error()
+    fl = sum(2.0 * m * k * M for m, k in shapes)
+    for nm, fn in (("four split-K launches", four), ("one grouped launch", one), ("four split-K launches", four), ("one grouped launch", one)):
+        us = timeit(fn)
+        print("wgrad of a block, K=%6d: %-22s %8.1f us  %7.1f TFLOP/s" % (M, nm, us, fl / us / 1e6))
+
+
 def bench_attn_fwd():
     qkv = rnd(M, 3 * E)
     o = torch.zeros(M, E, device="cuda", dtype=torch.bfloat16)
@@ -173,6 +200,8 @@ if __name__ == "__main__":
         bench_gemm_fwd()
     if "gemmdiag" in what:
         bench_gemm_diag()
+    if "wgradgroup" in what:
+        bench_wgrad_group()
     if "wgraddiag" in what:
         bench_wgrad_diag()
     if "attn" in what:
