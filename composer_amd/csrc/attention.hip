@@ -611,6 +611,10 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     }
 }
 
+#ifdef COMPOSER_EXPERIMENTS
+// Three more forward structures for bf16 / D = 64, built and measured in round 3 (profiles/NEGATIVE_RESULTS.md, "Attention"): none beats
+// the kernel above.  They are NOT part of the product library: `python tools/ab_build.py <name> attention.hip -DCOMPOSER_EXPERIMENTS`
+// builds a library that has them (COMPOSER_ATTN64=force|pipe|dense selects one), tests/extra/test_gpu_attn64.py runs them.
 // =================================================================================================
 // forward, bf16 / D = 64, second structure ("fwd64").  What round 2 measured on the kernel above: no pipe is busy (matrix
 // 25 %, vector ~30-50 %, LDS 33 %) -- the waves wait: for the register-staged K/V loads (-26 % without them), for the
@@ -1301,6 +1305,8 @@ __global__ __launch_bounds__(256, A4_MINW) void attn_fwd32d_kernel(const bf16_t*
     }
 }
 
+#endif  // COMPOSER_EXPERIMENTS
+
 // =================================================================================================
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
 // With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
@@ -1604,6 +1610,7 @@ static int attn_grid_x(int Tn, int BH) {
     const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2;
     return (nb > 1 && (int64_t)pairs * BH < 512) ? nb : pairs;
 }
+#ifdef COMPOSER_EXPERIMENTS
 // COMPOSER_ATTN64=force (read per call) takes the 64-rows-per-wave LDS-DMA forward kernel below (tests/test_gpu_attn64.py runs
 // every shape through it).  It is NOT the default: measured on one box at the C2 shape (B*H = 1024, T = 1024), 289 us without
 // dropout against 264-300 for the kernel above, and 528 us with dropout (its mask arithmetic pushes the 64-row state past 256
@@ -1613,8 +1620,10 @@ static int attn64_mode() {
     if (!e) return 0;
     return e[0] == 'o' ? -1 : (e[0] == 'f' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'd' ? 3 : 0)));
 }
+#endif
 template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
+#ifdef COMPOSER_EXPERIMENTS
     if constexpr (std::is_same<T, bf16_t>::value && D == 64) {
         const int nb = cdiv(Tn, 256), pairs = (nb + 1) / 2;
         const int mode = attn64_mode();
@@ -1672,6 +1681,7 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
             return CMP_OK;
         }
     }
+#endif
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem > 65536) {
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

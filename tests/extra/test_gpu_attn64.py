@@ -3,9 +3,14 @@ heuristic sends only chip-filling launches to them; COMPOSER_ATTN64=force makes 
 parity tests (float64 restatement of transformer.py:331-371 with the exact -1e4 mask, bit-identical dropout masks) take them
 too, and the full-length BASELINE shapes are run both ways."""
 import os
+import sys
 import pytest
 import torch
 
+# NOT part of the default suite: these kernels exist only in a library built with -DCOMPOSER_EXPERIMENTS
+#   python tools/ab_build.py experiments attention.hip -DCOMPOSER_EXPERIMENTS
+#   COMPOSER_HIP_LIB=composer_amd/lib/experiments.so python -m pytest tests/extra/test_gpu_attn64.py -m gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import test_gpu_kernels as K
 
 pytestmark = pytest.mark.gpu
