@@ -17,7 +17,8 @@
 //   "transposed" A operands (V^T, K^T, Q^T, dO^T) come from row-major LDS images through
 //   ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (fp32).
 #include "common.h"
-#ifndef ATTN_DIAG
+#if !defined(COMPOSER_EXPERIMENTS) || !defined(ATTN_DIAG)      // measurement ladders exist in experiments builds only
+#undef ATTN_DIAG
 #define ATTN_DIAG 0
 #endif
 

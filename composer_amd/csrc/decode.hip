@@ -84,6 +84,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     }
 }
 
+#ifdef COMPOSER_EXPERIMENTS      // first-generation decode kernels (COMPOSER_DECODE_V1=1 in an experiments build): K cache [H][W][D]
 // K/V of the prompt from the prefill's c_attn output [P][3E] (activation dtype) into the cache [H][W][D]
 template <typename T>
 __global__ void cache_fill_kernel(const T* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc, int P, int E,
@@ -94,6 +95,7 @@ __global__ void cache_fill_kernel(const T* __restrict__ qkv, float* __restrict__
     kc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + E + e]);
     vc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + 2 * E + e]);
 }
+#endif
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
     }
 }
 
+#ifdef COMPOSER_EXPERIMENTS      // first-generation attention and sampler kernels
 // Split-key single-query attention: grid (H, ATT_SPLITS).  Workgroup (h, s) owns keys [s*chunk, (s+1)*chunk) of head h
 // (chunk = W/ATT_SPLITS); the one that owns position `pos` appends this token's k,v to the cache.  Scores: 16 lanes
 // cooperate on one key (16-byte coalesced reads of the [W][D] cache rows, D <= 64... 128 via two passes), 4 keys per
@@ -374,10 +377,11 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict
     if (pos >= st->W) pos = st->W - 1;   // host refuses to step past the table; never index outside it
     for (int e = tid; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)pos * E + e];
 }
+#endif  // COMPOSER_EXPERIMENTS
 
 
 // =================================================================================================
-// Second-generation per-token kernels (default).  Same arithmetic; every kernel's dependent chain is as short as the
+// The per-token kernels (second generation; the first one is kept in experiments builds for A/B timing).  Same arithmetic; every kernel's dependent chain is as short as the
 // data flow allows, because a batch-1 token is 5L+2 dependent launches of ~1.8 us boundary each (tools/ubench/graph_chain.hip)
 // and what is left to win is inside the kernels:
 //   * GEMV: a workgroup is 1-4 INDEPENDENT waves, one output column per wave: no LDS, no barrier.  Each lane loads the
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict
 //   * attention: the K cache is stored [H][D/4][W][4] so that TWO lanes own a key (one DPP add per score instead of a
 //     16-lane shuffle tree); each wave runs its own online softmax over its keys and the four waves meet at ONE barrier;
 //     the current token's k/v come from the c_attn output instead of a write -> barrier -> read through the cache.
-// COMPOSER_DECODE_V1=1 selects the first-generation kernels above (A/B timing on one box).
+// In an experiments build (-DCOMPOSER_EXPERIMENTS) COMPOSER_DECODE_V1=1 selects the first-generation kernels above.
 // =================================================================================================
 #define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 #define DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
@@ -780,10 +784,12 @@ static int launch_attn2(hipStream_t s, cmp_model* m, DecodeState* d, const DecLa
 
 static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
     hipStream_t s = m->ctx->stream;
-    // COMPOSER_DECODE_DIAG_SKIP (timing diagnosis only -- the ids are wrong): bit 0 LN1+c_attn, 1 attention, 2 c_proj,
-    // 3 LN2+c_fc, 4 mlp c_proj, 5 logits, 6 sampler are left out of the captured chain
+    // COMPOSER_DECODE_DIAG_SKIP (experiments builds only; timing diagnosis -- the ids are wrong): bit 0 LN1+c_attn, 1 attention,
+    // 2 c_proj, 3 LN2+c_fc, 4 mlp c_proj, 5 logits, 6 sampler are left out of the captured chain
     int skip = 0;
+#ifdef COMPOSER_EXPERIMENTS
     { const char* e = getenv("COMPOSER_DECODE_DIAG_SKIP"); if (e) skip = atoi(e); }
+#endif
     const int E = m->E, Ea = m->Ea, L = m->L;
     const bool ln = m->cfg.use_layer_norm != 0;
     const float eps = m->cfg.ln_eps;
@@ -814,6 +820,10 @@ static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
 // one token: consumes d->x (embedding of st->token at st->pos), produces the next id and the next d->x
 static int enqueue_token_step(cmp_model* m, DecodeState* d) {
     if (!d->v1) return enqueue_token_step2(m, d);
+#ifndef COMPOSER_EXPERIMENTS
+    cmp_set_error("decode: the first-generation kernels exist only in an experiments build");
+    return CMP_ERR_STATE;
+#else
     hipStream_t s = m->ctx->stream;
     const int E = m->E, Ea = m->Ea, L = m->L;
     const bool ln = m->cfg.use_layer_norm != 0;
@@ -838,6 +848,7 @@ static int enqueue_token_step(cmp_model* m, DecodeState* d) {
                                         m->P + m->off_wpe, d->x, E, 0);
     KERNEL_CHECK();
     return CMP_OK;
+#endif
 }
 
 extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int mode, float temperature, uint64_t seed) {
@@ -853,7 +864,11 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     // transposes, capture + instantiate: 6 % of a 1024-token generate) what is left is the prefill.  The transposes are
     // redone when a parameter has changed since (cmp_model::param_version); the chain is re-captured only when the kernel
     // generation or the graph switch changes (temperature, seed and mode live in the device-side state).
+#ifdef COMPOSER_EXPERIMENTS
     const bool v1 = [] { const char* e = getenv("COMPOSER_DECODE_V1"); return e && e[0] == '1'; }();
+#else
+    const bool v1 = false;
+#endif
     const bool graph_on = [] { const char* e = getenv("COMPOSER_NO_GRAPH"); return !(e && e[0] == '1'); }();
     DecodeState* d = m->dec;
     if (d && !d->built) {                       // an earlier call failed part-way (an allocation, the capture): start over
@@ -921,12 +936,15 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     if (mode == CMP_DECODE_KV) {
         for (int i = 0; i < L; i++) {
             int grid = cdiv(P * Ea, 256);
+#ifdef COMPOSER_EXPERIMENTS
             if (d->v1) {
                 if (m->dtype == CMP_BF16)
                     cache_fill_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
                 else
                     cache_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
-            } else {
+            } else
+#endif
+            {
                 if (m->dtype == CMP_BF16)
                     cache_fill2_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
                 else
@@ -947,8 +965,11 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     h.seed = (unsigned)seed;
     HIP_CHECK(hipMemcpyAsync(d->st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     // first id from the last prompt row (cli.py:673 `[-1, 0]`)
+#ifdef COMPOSER_EXPERIMENTS
     if (d->v1) dec_sample_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, d->st, d->ids, m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
-    else dec_sample2_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, d->st, d->ids, m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
+    else
+#endif
+    dec_sample2_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, d->st, d->ids, m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(s));
     d->produced = 1;

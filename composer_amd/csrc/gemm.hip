@@ -842,7 +842,8 @@ struct ItemPuller {
 //   * same LDS images / swizzles / direct-to-LDS staging / range-checked descriptors as the 128^2 fast path.
 // LDS: 2 stages x (A 32 KiB + B 32 KiB) = 128 KiB.
 // =================================================================================================
-#ifndef GEMM_DIAG
+#if !defined(COMPOSER_EXPERIMENTS) || !defined(GEMM_DIAG)      // measurement ladders exist in experiments builds only
+#undef GEMM_DIAG
 #define GEMM_DIAG 0
 #endif
 #define H_BM 256
@@ -1415,7 +1416,8 @@ __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __res
                 stamp(11);
                 __builtin_amdgcn_s_barrier();
                 stamp(12);
-#ifndef P4_DIAG
+#if !defined(COMPOSER_EXPERIMENTS) || !defined(P4_DIAG)      // measurement ladders exist in experiments builds only
+#undef P4_DIAG
 #define P4_DIAG 0
 #endif
                 do_issue = t + AHEAD < n && P4_DIAG != 3;       // P4_DIAG (measurement builds, wrong results): 1 no MFMA, 3 no DMA in the k-loop

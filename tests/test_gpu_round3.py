@@ -516,13 +516,11 @@ def test_decode_to_the_last_position_of_a_long_window():
 
 
 @pytest.mark.parametrize("E,H", [(1024, 8), (2048, 16), (1000, 10)])
-@pytest.mark.parametrize("v1", [False, True])
-def test_decode_of_wide_models(E, H, v1, monkeypatch):
+def test_decode_of_wide_models(E, H):
     """Models wider than 768: the per-token GEMV over 4E inputs (mlp c_proj) no longer fits one register-resident pass and takes
-    the staged kernel in several passes; E = 1000 with 10 heads also runs its 100-wide heads zero-padded to 128.  Greedy ids of
-    both decode modes against the oracle, with either kernel generation."""
+    the staged kernel in several passes; E = 1000 with 10 heads also runs its 100-wide heads zero-padded to 128; the fused
+    LN_f + logits + sampler launch runs its wide-row instantiation.  Greedy ids of both decode modes against the oracle."""
     from test_gpu_model import make_model
-    monkeypatch.setenv("COMPOSER_DECODE_V1", "1" if v1 else "0")
     V, L, W = 390, 1, 12
     params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=E, stddev=0.05).items()}
     prompt = np.random.default_rng(E).integers(0, V, size=5).astype(np.int32)
