@@ -1810,11 +1810,36 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
             for (int tm = 0; tm < cdiv(probs[i].M, 256); tm++)
                 for (int tn = 0; tn < cdiv(probs[i].N, 256); tn++) tiles.push_back({i, tm * 256, tn * 256});
         const int T = (int)tiles.size(), nk = K / P_BK;
-        const int sp = std::max(1, std::min(G / T, nk)), chunk = cdiv(nk, sp), nsp = cdiv(nk, chunk);
-        const int nitems = T * nsp;
+        const int sp = std::max(1, std::min(G / T, nk));
+        // Workgroups left over by the common split count (C2: 256 - 48 * 5 = 16) go to whole PROBLEMS, smallest first, as one
+        // more split each (tiles that share operand panels keep the same K ranges): their items are shorter, finish early and
+        // put their share of the atomic traffic out before the final burst; the longest item is unchanged.
+        std::vector<int> tiles_of(nprob, 0), split_of(nprob, sp);
+        for (const Seg& t : tiles) tiles_of[t.prob]++;
+        {
+            int spare = G - T * sp;
+            std::vector<int> byt(nprob);
+            for (int i = 0; i < nprob; i++) byt[i] = i;
+            std::stable_sort(byt.begin(), byt.end(), [&](int a, int b) { return tiles_of[a] < tiles_of[b]; });
+            for (int i : byt)
+                if (T * sp <= G && sp + 1 <= nk && tiles_of[i] <= spare) { split_of[i] = sp + 1; spare -= tiles_of[i]; }
+        }
+        // items in K-range-major order (range j of every problem that has one, tile by tile): consecutive items = one XCD's group
+        struct Item { int tile, kt0, kt1; };
+        std::vector<Item> order;
+        int max_split = 0, longest = 0;
+        for (int i = 0; i < nprob; i++) max_split = std::max(max_split, split_of[i]);
+        for (int j = 0; j < max_split; j++)
+            for (int t = 0; t < T; t++) {
+                const int spt = split_of[tiles[t].prob], chunk = cdiv(nk, spt);
+                if (j * chunk >= nk) continue;
+                order.push_back({t, j * chunk, std::min(nk, (j + 1) * chunk)});
+                longest = std::max(longest, std::min(nk, (j + 1) * chunk) - j * chunk);
+            }
+        const int nitems = (int)order.size();
         {   // is one grouped launch cheaper than one split-K launch per problem?  (model above; K-independent overhead in k-steps)
             const double ov = 59.0;
-            const double grouped = (double)chunk * cdiv(nitems, G) + ov;
+            const double grouped = (double)longest * cdiv(nitems, G) + ov;
             double separate = 0.0;
             for (int i = 0; i < nprob; i++) {
                 const int t = cdiv(probs[i].M, 256) * cdiv(probs[i].N, 256);
@@ -1837,8 +1862,8 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
         for (int item = 0; item < nitems; item++) {
             const int x = item & 7;                                        // the XCD group of the item (ItemPuller): consecutive lin per group
             const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
-            const int j = lin / T, t = lin - j * T;
-            hi[item] = make_int4(tiles[t].prob, tiles[t].m0 | (tiles[t].n0 << 16), j * chunk, std::min(nk, (j + 1) * chunk));
+            const Item& it = order[lin];
+            hi[item] = make_int4(tiles[it.tile].prob, tiles[it.tile].m0 | (tiles[it.tile].n0 << 16), it.kt0, it.kt1);
         }
         HIP_CHECK(hipStreamSynchronize(s));            // the previous table of this group may still be in use / in flight (a rebuild is rare)
         if (g->dev_bytes < host.size()) {
