@@ -122,6 +122,22 @@ def test_grouped_weight_gradients(lib, K, shapes):
         assert rel_err(c[:-1], c0[:-1].double() + 2 * (a.double().cpu().T @ b.double().cpu())) < 4e-5
 
 
+def test_grouped_weight_gradients_with_item_counters(lib, monkeypatch):
+    """The grouped launch with its items claimed from the per-XCD counters (what a data-parallel job uses: COMPOSER_GEMM_ITEMS=dynamic
+    forces it here) gives the products of the statically strided launch; repeated launches alternate the two counter sets."""
+    K, shapes = 4096, [(512, 2048), (2048, 512), (512, 512), (512, 1536)]
+    g = torch.Generator().manual_seed(3)
+    As = [torch.randn(K, m, generator=g).to(torch.bfloat16).cuda() for m, n in shapes]
+    Bs = [torch.randn(K, n, generator=g).to(torch.bfloat16).cuda() for m, n in shapes]
+    refs = [a.double().cpu().T @ b.double().cpu() for a, b in zip(As, Bs)]
+    monkeypatch.setenv("COMPOSER_GEMM_ITEMS", "dynamic")
+    for rep in range(5):
+        Cs = [torch.zeros(m, n, device="cuda") for m, n in shapes]
+        wgrad_group(lib, As, Bs, Cs, K)
+        for c, ref in zip(Cs, refs):
+            assert rel_err(c, ref) < 2e-5, rep
+
+
 def test_grouped_weight_gradients_at_the_timed_depth(lib):
     """The C2 block at K = 131 072 tokens (bench.py's geometry): every problem against its float64 product."""
     K = 131072
