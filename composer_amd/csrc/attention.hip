@@ -1384,7 +1384,12 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
         if (qvalid && h == 0) delta[(int64_t)by * Tn + q] = dsum;
         const float del_q = (qvalid ? dsum : 0.f) / keep_scale;
         __syncthreads();
-        for (int kt0 = 0, it = 0; kt0 < kv_end; kt0 += 64, it++) {
+        // One 64-key tile.  `interior` (compile time) = every key of the tile lies at or below every query row of the block and
+        // every row and key exists: that instance carries NO mask code.  (Round 3 had the mask in one loop under a wave-uniform
+        // `if (edge)`: hipcc if-converted it -- 32 integer compares + 16 selects + ~17 scalar mask operations in the block of the
+        // score MFMAs of EVERY sub-tile, a fifth of the kernel's vector instructions, needed on two tiles in eighteen.)
+        auto tile = [&](auto interior, const int kt0, const int it) __attribute__((always_inline)) {
+            constexpr bool INT = decltype(interior)::value;
             const T* Ks = Kb + (it & 1) * 2 * IMG;
             const T* Vs = Ks + IMG;
             const bool more = kt0 + 64 < kv_end;
@@ -1395,7 +1400,7 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
                 const int k0 = kt0 + 32 * sub;
-                if (k0 > q0w + 31 || k0 >= Tn) continue;
+                if (!INT && (k0 > q0w + 31 || k0 >= Tn)) continue;
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
@@ -1411,16 +1416,16 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                         s[r] = p * (dp[r] - del_q);
                     }
                 } else {
-                    // the mask is applied in its own loop under ONE wave-uniform branch: inside the element loop hipcc
-                    // emitted a scalar branch per element (15 s_cbranch per sub-tile in the ISA)
-                    const bool edge = (k0 + 31 > q0w) || (k0 + 32 > Tn) || (q0w + 32 > Tn);
 #pragma unroll
                     for (int r = 0; r < 16; r++) s[r] = fast_exp2(fmaf(s[r], c2, -lse2));
-                    if (edge) {
+                    if constexpr (!INT) {
+                        const bool edge = (k0 + 31 > q0w) || (k0 + 32 > Tn) || (q0w + 32 > Tn);      // wave-uniform
+                        if (edge) {
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int key = k0 + rho(r, h);
-                            if ((key > q) || (key >= Tn) || !qvalid) s[r] = 0.f;
+                            for (int r = 0; r < 16; r++) {
+                                const int key = k0 + rho(r, h);
+                                if ((key > q) || (key >= Tn) || !qvalid) s[r] = 0.f;
+                            }
                         }
                     }
 #pragma unroll
@@ -1435,7 +1440,11 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                 sv.store(nbuf + IMG, tid);
             }
             __syncthreads();
-        }
+        };
+        int kt0 = 0, it = 0;
+        const int interior_end = (EXACT || qb * 128 + 128 > Tn) ? 0 : qb * 128;     // keys below every (existing) query row of the block
+        for (; kt0 < interior_end; kt0 += 64, it++) tile(std::true_type{}, kt0, it);
+        for (; kt0 < kv_end; kt0 += 64, it++) tile(std::false_type{}, kt0, it);
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale * keep_scale, h);
         if (bias_grad) colsum_t_tiles<T, D>(bias_grad + hd * D, qvalid, dq, scale * keep_scale, h, lane);
@@ -1521,7 +1530,11 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
         so.store(Qb + IMG, tid);
         store_rows(Lb, qstart);
         __syncthreads();
-        for (int qt0 = qstart, it = 0; qt0 < Tn; qt0 += 64, it++) {
+        // One 64-query tile.  `interior` (compile time) = every query row of the tile lies below every key of the block and every
+        // row and key exists: no mask code in that instance (see the dQ kernel: the if-converted mask was a fifth of the vector
+        // instructions of every sub-tile).
+        auto tile = [&](auto interior, const int qt0, const int it) __attribute__((always_inline)) {
+            constexpr bool INT = decltype(interior)::value;
             const T* Qs = Qb + (it & 1) * 2 * IMG;
             const T* Os = Qs + IMG;
             const float* Ls = Lb + (it & 1) * 192;
@@ -1534,7 +1547,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
                 const int qb0 = qt0 + 32 * sub;
-                if (qb0 + 31 < k0w || qb0 >= Tn || k0w >= Tn) continue;     // wave-uniform: all (q, key) pairs masked
+                if (!INT && (qb0 + 31 < k0w || qb0 >= Tn || k0w >= Tn)) continue;     // wave-uniform: all (q, key) pairs masked
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
@@ -1550,32 +1563,43 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
                     dq4[g] = *reinterpret_cast<const f32x4*>(Ls + 64 + ql);
                     if constexpr (DROP) rh4[g] = *reinterpret_cast<const __attribute__((ext_vector_type(4))) uint32_t*>(Ls + 128 + ql);
                 }
-                const bool edge = EXACT || (qb0 < k0w + 32) || (qb0 + 32 > Tn) || (k0w + 32 > Tn);   // wave-uniform
                 f32x16 pt;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     if constexpr (EXACT) pt[r] = expf(s[r] * scale - lq[r >> 2][r & 3]);
                     else pt[r] = fast_exp2(fmaf(s[r], c2, -lq[r >> 2][r & 3]));        // lse*log2(e) in this mode
                 }
-                if (edge) {          // one wave-uniform branch around the whole mask loop (see the dQ kernel)
+                if constexpr (!INT) {
+                    const bool edge = EXACT || (qb0 < k0w + 32) || (qb0 + 32 > Tn) || (k0w + 32 > Tn);   // wave-uniform
+                    if (edge) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int qq = qt0 + 32 * sub + rho(r, h);
-                        if ((key > qq) || (qq >= Tn) || !kvalid) pt[r] = 0.f;
+                        for (int r = 0; r < 16; r++) {
+                            const int qq = qt0 + 32 * sub + rho(r, h);
+                            if ((key > qq) || (qq >= Tn) || !kvalid) pt[r] = 0.f;
+                        }
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const float p = pt[r];
-                    float dpv = dp[r];
-                    float pd = p;
-                    if constexpr (DROP) {
+                    if constexpr (EXACT || !DROP) {
+                        float dpv = dp[r];
+                        float pd = p;
+                        if constexpr (DROP) {
+                            const bool keep = __umul24(rh4[r >> 2][r & 3] ^ kgG, kC) >= drop.thr;
+                            dpv = keep ? dpv : 0.f;
+                            pd = keep ? p : 0.f;
+                        }
+                        pt[r] = pd;                                   // (dropped) probabilities feed dV
+                        s[r] = p * (dpv - dq4[r >> 2][r & 3]);        // dS/f feeds dK
+                    } else {
+                        // p (M dP~ - delta/f) = (M p) dP~ - p delta/f: ONE select (the masked probability, which dV needs anyway), a
+                        // multiply and an fma instead of two selects, a subtract and a multiply
                         const bool keep = __umul24(rh4[r >> 2][r & 3] ^ kgG, kC) >= drop.thr;
-                        dpv = keep ? dpv : 0.f;
-                        pd = keep ? p : 0.f;
+                        const float pd = keep ? p : 0.f;
+                        pt[r] = pd;
+                        s[r] = fmaf(pd, dp[r], -(p * dq4[r >> 2][r & 3]));
                     }
-                    pt[r] = pd;                                   // (dropped) probabilities feed dV
-                    s[r] = p * (dpv - dq4[r >> 2][r & 3]);        // dS/f feeds dK
                 }
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) {
@@ -1590,7 +1614,13 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
                 store_rows(Lb + ((it & 1) ^ 1) * 192, qt0 + 64);
             }
             __syncthreads();
-        }
+        };
+        // the diagonal block's tiles (masked), then the tiles below it (interior), then a ragged last tile (masked)
+        int qt0 = qstart, it = 0;
+        const int diag_end = EXACT ? Tn : min(Tn, qstart + 128);
+        for (; qt0 < diag_end; qt0 += 64, it++) tile(std::false_type{}, qt0, it);
+        for (; qt0 + 64 <= Tn; qt0 += 64, it++) tile(std::true_type{}, qt0, it);
+        for (; qt0 < Tn; qt0 += 64, it++) tile(std::false_type{}, qt0, it);
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) {
             store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale * keep_scale, h);
