@@ -78,6 +78,7 @@ SIGNATURES = {
     "cmp_prof_end2": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cmp_k_embed_fwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_embed_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_k_embed_bwd_v": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _f, _u64, _u32, _i]),
     "cmp_k_layernorm_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _f, _i]),
     "cmp_k_layernorm_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i]),
     "cmp_k_layernorm_bwd_ws": (_i64, [_i, _i]),
@@ -97,7 +98,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_dp_stats", "cmp_prof_end2", "cmp_k_wgrad_group"}
+_ADDED_LATER = {"cmp_dp_stats", "cmp_prof_end2", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
 
 _lib = None
 

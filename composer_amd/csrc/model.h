@@ -109,6 +109,8 @@ struct cmp_model {
     float *logits = nullptr, *lnf_mean = nullptr, *lnf_rstd = nullptr, *row_loss = nullptr, *delta = nullptr;
     int32_t *row_correct = nullptr, *x_dev = nullptr, *y_dev = nullptr;
     void *dx = nullptr, *dr = nullptr, *tmpE = nullptr, *dmask = nullptr, *dfc = nullptr, *dqkv = nullptr;
+    int* embed_ws = nullptr;           // workspace of the sorted embedding backward (elementwise.hip: embed_bwd_sort_ws_words)
+    int64_t embed_ws_words = 0;
     void* dmask2 = nullptr;            // the attention branch's masked gradient: both masked copies of a block stay live until its grouped wgrad launch
     std::vector<WgradGroup> wgrad_groups;      // per decoder block: item table + problem descriptors of that launch
     void* ln_ws = nullptr;
@@ -162,7 +164,9 @@ template <typename Tp> static int dev_alloc(cmp_model* m, Tp** p, size_t bytes) 
 
 // elementwise.hip
 int embed_bwd_run(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe, int B, int T, int E, int pos0,
-                  int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, int V, float* det_ws, size_t det_ws_bytes);
+                  int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, int V, float* det_ws, size_t det_ws_bytes,
+                  int sort_V = 0, int* sort_ws = nullptr, int64_t sort_ws_words = 0);
+int64_t embed_bwd_sort_ws_words(int64_t ntok, int V);
 int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* resid, void* dx, float* dgamma, float* dbeta, void* ws, int rows, int E, int dtype, void* dmask,
                       float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic);

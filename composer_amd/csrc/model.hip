@@ -544,6 +544,8 @@ static int ensure_workspace_fill(cmp_model* m, int B, int T) {
         }
     }
     CHECK_RC(dev_alloc(m, &m->ln_ws, (size_t)cmp_k_layernorm_bwd_ws((int)std::min<int64_t>(M, 1 << 30), E)));
+    m->embed_ws_words = embed_bwd_sort_ws_words(M, m->V);
+    if (m->embed_ws_words > 0) CHECK_RC(dev_alloc(m, &m->embed_ws, (size_t)m->embed_ws_words * 4));
     return CMP_OK;
 }
 
@@ -868,7 +870,8 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end, lr));
     }
     CHECK_RC(embed_bwd_run(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->drop_seed(),
-                           drop_stream(step, 0, 0), m->slab ? V : 0, (float*)m->slab, (size_t)m->slab_bytes));
+                           drop_stream(step, 0, 0), m->slab ? V : 0, (float*)m->slab, (size_t)m->slab_bytes, V, m->embed_ws,
+                           m->embed_ws_words));
     if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin, lr));
     return CMP_OK;
 }

@@ -191,6 +191,10 @@ int cmp_k_embed_fwd(void* stream, const int32_t* ids, const float* wte, const fl
                     int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream);
 int cmp_k_embed_bwd(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe,
                     int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream);
+/* the same through the sorted form the model uses for batches of 4096 tokens or more (tokens counting-sorted by id, rows of one id
+ * summed before they are added: E f32 atomics per 32 rows instead of one per element); V = vocabulary size (<= 8192) */
+int cmp_k_embed_bwd_v(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe,
+                      int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, int V);
 int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, int rows, int E, float eps, int dtype);
 /* dx = resid(optional) + LN_bwd(dy); dgamma/dbeta fp32 [E] are ACCUMULATED into; ws >= cmp_k_layernorm_bwd_ws bytes */

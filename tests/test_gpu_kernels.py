@@ -522,6 +522,34 @@ def test_embedding_fwd_bwd(lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", [FP32, BF16])
+@pytest.mark.parametrize("B,T,E,V,p", [(8, 512, 512, 390, 0.3), (5, 1000, 768, 1384, 0.0), (33, 128, 64, 3, 0.1), (2, 2048, 1024, 8000, 0.2),
+                                       (16, 256, 2048, 390, 0.0)])
+def test_embedding_bwd_sorted_form(lib, dtype, B, T, E, V, p):
+    """cmp_k_embed_bwd_v: the form the model's backward pass uses from 4096 tokens on -- tokens counting-sorted by id, up to 32 rows
+    of one id summed by a workgroup before E atomics, position gradient as a per-position batch sum -- against float64 index_add /
+    batch sums with the oracle's dropout masks; ids skewed (half the tokens share three ids), ids that never occur, and the
+    gradients ACCUMULATE into what the buffers hold (the tied logits gradient is already in dwte when the model gets here)."""
+    g = torch.Generator().manual_seed(B * T + V)
+    ids = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32)
+    hot = torch.rand(B, T, generator=g) < 0.5
+    ids[hot] = torch.randint(0, min(V, 3), (int(hot.sum()),), generator=g, dtype=torch.int32)
+    W = T + 5
+    dh = dev(torch.randn(B * T, E, generator=g), dtype)
+    dwte0, dwpe0 = torch.randn(V, E, generator=g), torch.randn(W, E, generator=g)
+    dwte, dwpe = dwte0.clone().cuda(), dwpe0.clone().cuda()
+    ids_d = dev(ids)
+    ck(lib, lib.cmp_k_embed_bwd_v(stream(), P(ids_d), P(dh), P(dwte), P(dwpe), B, T, E, 2, dtype, p, 5, 2, V))
+    torch.cuda.synchronize()
+    d = dh.double().cpu()
+    if p > 0:
+        d = d * torch.tensor(O.dropout_keep_rows(5, 2, B * T, E, p) / (1 - p))
+    rw = dwte0.double().clone(); rw.index_add_(0, ids.reshape(-1).long(), d)
+    rp = dwpe0.double().clone(); rp[2:2 + T] += d.reshape(B, T, E).sum(0)
+    assert rel_err(dwte, rw) < 2e-5 and rel_err(dwpe, rp) < 2e-5
+    assert torch.equal(dwpe[:2].cpu(), dwpe0[:2]) and torch.equal(dwpe[2 + T:].cpu(), dwpe0[2 + T:])
+
+
+@pytest.mark.parametrize("dtype", [FP32, BF16])
 def test_colsum(lib, dtype):
     rows, cols = 1000, 392
     x = dev(torch.randn(rows, cols), dtype)
