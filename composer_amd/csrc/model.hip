@@ -769,8 +769,20 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     const bool ln = m->cfg.use_layer_norm != 0;
     HIP_CHECK(hipMemsetAsync(m->G, 0, (size_t)m->total * 4, s));
     // tied logits: dwte += dZ^T.hf ; dhf = dZ.wte
-    CHECK_RC(gemm(m, 1, 0, V, E, M, m->dlogits, m->ldz, m->hf, E, m->G + m->off_wte, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
-                  std::max(2, wgrad_splits(M, V, E)), 0.f, 0));
+    {
+        // few output tiles (390 x 512 = 4 of 256x256): on the 128x128 kernel the launch is 768 workgroups of a 48th of the tokens each
+        // (1.5 rounds, 48 MB of atomics); on the persistent 256x256 deep-pipeline kernel one item per CU
+#ifdef COMPOSER_TIED_WGRAD_OLD
+        const int tsplit = std::max(2, wgrad_splits(M, V, E)), tflags = 0;
+#else
+        const int t256 = cdiv(V, 256) * cdiv(E, 256);
+        const bool p4 = dt == CMP_BF16 && t256 <= 64 && M >= 65536 && M % 32 == 0;       // (at 32 768 tokens the two forms tie)
+        const int tsplit = p4 ? std::max(2, std::min(256 / t256, M / 1024)) : std::max(2, wgrad_splits(M, V, E));
+        const int tflags = p4 ? CMP_GEMM_P4 : 0;
+#endif
+        CHECK_RC(gemm(m, 1, 0, V, E, M, m->dlogits, m->ldz, m->hf, E, m->G + m->off_wte, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
+                      tsplit, 0.f, 0, tflags));
+    }
     CHECK_RC(gemm(m, 0, 0, M, E, V, m->dlogits, m->ldz, m->w(m->off_wte), E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr, 0, 0,
                   1, 0.f, 0, CMP_GEMM_KPAD_ZERO));    // dlogits rows are zero-padded to ldz (softmax_xent kernel)
     // dx of every LayerNorm backward below is the gradient of the previous residual branch's dropout output, so the
