@@ -63,10 +63,22 @@ extern "C" int cmp_prof_begin(int cls) {
     g_prof_bytes = 0.0;
     return CMP_OK;
 }
+// between cmp_prof_begin and cmp_prof_end: stop / continue recording without touching what has been recorded (bench.py times
+// every n-th step of its timed region: two events per launch are not free)
+static thread_local int g_prof_armed = -1;
+extern "C" int cmp_prof_pause(void) {
+    if (g_prof_cls >= 0) { g_prof_armed = g_prof_cls; g_prof_cls = -1; }
+    return CMP_OK;
+}
+extern "C" int cmp_prof_resume(void) {
+    if (g_prof_armed >= 0) { g_prof_cls = g_prof_armed; g_prof_armed = -1; }
+    return CMP_OK;
+}
 extern "C" int cmp_prof_end2(double* total_ms, int64_t* launches, double* work, double* bytes);
 extern "C" int cmp_prof_end(double* total_ms, int64_t* launches, double* work) { return cmp_prof_end2(total_ms, launches, work, nullptr); }
 extern "C" int cmp_prof_end2(double* total_ms, int64_t* launches, double* work, double* bytes) {
     g_prof_cls = -1;
+    g_prof_armed = -1;
     if (g_prof_used >= 2) HIP_CHECK(hipEventSynchronize(g_prof_ev[g_prof_used - 1]));       // the last recorded stop event (same stream order)
     double t = 0.0;
     for (size_t i = 0; i + 1 < g_prof_used; i += 2) {

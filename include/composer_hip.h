@@ -184,6 +184,9 @@ int cmp_prof_end(double* total_ms, int64_t* launches, double* work);
 /* the same, and the summed ALGORITHMIC HBM bytes of those launches (every operand read once, every result written once):
  * what bench.py's per-class `algorithmic_bytes` is, next to the PMC-measured `traffic`.  Class 8 = layernorm backward. */
 int cmp_prof_end2(double* total_ms, int64_t* launches, double* work, double* bytes);
+/* between begin and end: stop / continue recording (what has been recorded stays); bench.py times a subset of its timed steps */
+int cmp_prof_pause(void);
+int cmp_prof_resume(void);
 
 /* ---- kernel-level entry points (dev pointers; dtype = cmp_dtype of activations) ----------------
  * Used by tests/ and bench.py to check and time single kernels against the oracle/roofline. */
