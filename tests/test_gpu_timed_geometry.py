@@ -93,6 +93,34 @@ def test_tiled_row_at_the_timed_batch_has_the_single_row_loss_and_gradients(cfg,
     mb.close()
 
 
+@pytest.mark.parametrize("B,T,E,H,L,p", [(32, 128, 64, 2, 2, 0.15), (9, 512, 128, 2, 1, 0.0), (48, 96, 96, 4, 2, 0.1)])
+def test_batches_that_take_the_grouped_and_sorted_kernels_match_the_oracle(B, T, E, H, L, p):
+    """From 4 096 tokens on the backward pass changes kernels: the embedding gradient goes through the sorted form, and in bf16 the
+    four weight gradients of a block through ONE grouped launch (tokens a multiple of 32).  Medium batches at which the float64
+    oracle is still quick: fp32 and bf16 (against the bf16-rounding oracle) loss and EVERY parameter gradient, dropout on in
+    two of the three, a head size without a kernel of its own (24) in the third."""
+    from composer_amd import _lib
+    from composer_amd.transformer import Transformer
+    W = T
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=B + T, stddev=0.08).items()}
+    rng = np.random.default_rng(B * T)
+    x, y = O.synthetic_batch(rng, V, B, T)
+    x[:, ::3] = x[0, 0]                                    # a third of the tokens share one id: a long run in the sorted token list
+    ocfg = O.Config(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p)
+    for dtype in ("fp32", "bf16"):
+        orc = O.OracleTransformer(ocfg, params, seed=7, emulate_bf16=(dtype == "bf16"))
+        loss, acc, G, _ = orc.loss_and_grads(x, y, training=p > 0, step=0)
+        m = Transformer(V, E, W, L, H, attention_dropout_rate=p, residual_dropout_rate=p, dtype=dtype, seed=7, max_batch=B, max_seq=T)
+        m.set_weights(params)
+        l2, _ = m.loss_and_grads(x, y)
+        assert abs(l2 - loss) <= (2e-5 if dtype == "fp32" else 2e-2) * abs(loss), (dtype, l2, loss)
+        worst = {n: np.abs(m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64) - G[n]).max() / (np.abs(G[n]).max() + 1e-12)
+                 for n in m.parameter_names}
+        bad = {n: w for n, w in worst.items() if not w <= (5e-4 if dtype == "fp32" else 4e-2)}
+        assert not bad, (dtype, bad)
+        m.close()
+
+
 @pytest.mark.parametrize("name,m,n", [("mlp c_proj", 2048, 512), ("c_fc", 512, 2048), ("attn c_proj", 512, 512), ("c_attn", 512, 1536)])
 def test_wgrad_contracts_over_131072_tokens_like_a_float64_product(lib, name, m, n):
     """dW = X^T.dY with X stored [tokens, m], dY [tokens, n], K = 131 072 tokens, split-K by f32 atomics with the split count the
