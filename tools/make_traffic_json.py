@@ -21,6 +21,8 @@ import sys
 
 
 def classify(name, phase):
+    if "gemm_wgrad_group" in name:
+        return 2                                        # the grouped weight gradients of a block (contraction over tokens)
     if "gemm_bf16" in name or "gemm_f32" in name:
         if phase == "fwd":
             return 0
