@@ -391,13 +391,49 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by, int H) {
 #endif
 }
 
+// Block plan of the forward and dQ launches (plan_u >= 0; 1-D grid, B*H a multiple of 8).  All paired workgroups cost the same
+// (nb+1 tiles), so a grid that is not a whole number of rounds over the resident slots (B*H = 1024: 4096 pairs over 768 slots =
+// 5.33 rounds; B*H = 256: 1.33) ends with most of the chip idle.  The plan takes the first plan_u (batch, head) rows of every
+// XCD out of the pairing: an XCD runs its paired rows first, then the single blocks of those rows heaviest level first
+// (all rows' block nb-1, then nb-2, ...), so the launch ends on the cheapest jobs (longest-processing-time order).
+// Workgroup L: xcd = L & 7, slot = L >> 3; gridDim.x = 8 * ((rows_per_xcd - plan_u) * pairs + plan_u * nb).
+__device__ __forceinline__ void attn_job(int plan_u, int nb, int H, int& by, int& qb0, int& qb1) {
+    if (plan_u < 0) {
+        int bx;
+        xcd_block(bx, by, H);
+        qb0 = pair_block(0, nb, bx);
+        qb1 = pair_block(1, nb, bx);
+        return;
+    }
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    const int pairs = (nb + 1) >> 1;
+    const int n_paired = (int)(gridDim.x >> 3) - plan_u * nb;
+    int row;
+    if (slot < n_paired) {
+        row = plan_u + slot / pairs;
+        const int x = slot % pairs, hi = nb - 1 - x;
+        qb0 = hi;
+        qb1 = x < hi ? x : -1;
+    } else {
+        const int s2 = slot - n_paired;
+        row = s2 % plan_u;
+        qb0 = nb - 1 - s2 / plan_u;
+        qb1 = -1;
+    }
+    by = row * 8 + xcd;
+#ifndef ATTN_NO_HEAD_ROTATE
+    const int bb = by / H;
+    by = bb * H + (by % H + bb) % H;
+#endif
+}
+
 // =================================================================================================
 // forward.  grid ((nb+1)/2, B*H), 256 threads: wave w owns query rows [qb*128 + 32w, +32)
 // =================================================================================================
 template <typename T, int D, bool DROP>
 __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
                                                                           float* __restrict__ lse, int Tn, int H,
-                                                                          float scale, DropCfg drop) {
+                                                                          float scale, DropCfg drop, int plan_u) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -405,8 +441,9 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     constexpr int IMG = 64 * G::S;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, by;
-    xcd_block(bx, by, H);
+    const int nb = cdiv(Tn, 128);
+    int by, qb0, qb1;
+    attn_job(plan_u, nb, H, by, qb0, qb1);
 #if ATTN_DIAG == 9                                   // measurement build: every batch row aliases row 0 or 1 (data set stays in L2 / MALL)
     const int b = (by / H) & 1, hd = by % H;
 #else
@@ -419,10 +456,9 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     const T* vg = qg + 2 * E;
     T* og = o + (int64_t)b * Tn * E + hd * D;
     const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
-    const int nb = cdiv(Tn, 128);
 
     for (int ph = 0; ph < 2; ph++) {
-        const int qb = pair_block(ph, nb, bx);
+        const int qb = ph == 0 ? qb0 : qb1;
         if (qb < 0) break;
         const int q0w = qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
@@ -1319,7 +1355,7 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                                          const float* __restrict__ lse,
                                                                          float* __restrict__ delta, T* __restrict__ dqkv,
                                                                          float* __restrict__ bias_grad, int Tn, int H, float scale,
-                                                                         DropCfg drop) {
+                                                                         DropCfg drop, int plan_u) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1327,8 +1363,9 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
     constexpr int IMG = 64 * G::S;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, by;
-    xcd_block(bx, by, H);
+    const int nb = cdiv(Tn, 128);
+    int by, qb0, qb1;
+    attn_job(plan_u, nb, H, by, qb0, qb1);
     const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
@@ -1339,10 +1376,9 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
     T* dqg = dqkv + (int64_t)b * Tn * rs + hd * D;
     const float c2 = scale * LOG2E_F;
     const float keep_scale = DROP ? drop.scale : 1.0f;
-    const int nb = cdiv(Tn, 128);
 
     for (int ph = 0; ph < 2; ph++) {
-        const int qb = pair_block(ph, nb, bx);
+        const int qb = ph == 0 ? qb0 : qb1;
         if (qb < 0) break;
         const int q0w = qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
@@ -1641,6 +1677,35 @@ static int attn_grid_x(int Tn, int BH) {
     const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2;
     return (nb > 1 && (int64_t)pairs * BH < 512) ? nb : pairs;
 }
+// The block plan of a forward / dQ launch (attn_job): how many (batch, head) rows per XCD run as single blocks behind the paired
+// ones.  An XCD's workgroups start in order on 32 CUs x wgs_per_cu slots; the paired rows fill whole rounds of those slots and
+// the rows of the last, partial round go unpaired (with less than one round of pairs: three quarters of the rows).  Measured
+// (tools/ubench/attn_plan_probe.py, outputs bit-identical): B*H = 256: forward 73.6 -> 68.7 us, dQ 87.8 -> 82.0; 512: 140 -> 131,
+// 171 -> 154; 1024: 286 -> 281, 321 -> 314; 128: 42 -> 38, 50 -> 46.  (A list-scheduling model of the launch predicted three times
+// these gains: workgroups of a partly filled round run faster, the slots are not independent machines.)
+// -1 = the plain 2-D grid (B*H not a multiple of 8, a single block, few rows, or the pairs already fill whole rounds).
+static int attn_plan_u(int Tn, int BH, int wgs_per_cu) {
+    const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2;
+    if (nb < 2 || (BH & 7) || (int64_t)pairs * BH < 512 || wgs_per_cu < 1) return -1;
+    const int rows_x = BH / 8, slots = 32 * wgs_per_cu;
+#if defined(COMPOSER_EXPERIMENTS)
+    if (const char* e = getenv("COMPOSER_ATTN_PLAN_U")) return std::min(atoi(e), rows_x);     // measurement override
+#endif
+    const int rounds = rows_x * pairs / slots;
+    const int paired_rows = rounds > 0 ? rounds * slots / pairs : rows_x / 4;
+    const int u = rows_x - paired_rows;
+    return u > 0 ? u : -1;
+}
+static dim3 attn_plan_grid(int Tn, int BH, int u) {
+    if (u < 0) return dim3(attn_grid_x(Tn, BH), BH);
+    const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2, rows_x = BH / 8;
+    return dim3(8 * ((rows_x - u) * pairs + u * nb), 1);
+}
+template <typename K> static int attn_wgs_per_cu(K kernel, size_t smem) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, smem) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 #ifdef COMPOSER_EXPERIMENTS
 // COMPOSER_ATTN64=force (read per call) takes the 64-rows-per-wave LDS-DMA forward kernel below (tests/test_gpu_attn64.py runs
 // every shape through it).  It is NOT the default: measured on one box at the C2 shape (B*H = 1024, T = 1024), 289 us without
@@ -1718,11 +1783,13 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-    dim3 grid(attn_grid_x(Tn, B * H), B * H);
+    static const int wgs_per_cu = attn_wgs_per_cu(attn_fwd_kernel<T, D, true>, smem);
+    const int plan_u = attn_plan_u(Tn, B * H, wgs_per_cu);
+    const dim3 grid = attn_plan_grid(Tn, B * H, plan_u);
     const double flops = 2.0 * B * H * (double)Tn * Tn * D;      // QK^T + PV on the unmasked half
     PROF_START(3, s);
-    if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
-    else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d);
+    if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u);
+    else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u);
     PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * D * sizeof(T) + 4.0));      // q, k, v in; o, lse out
     KERNEL_CHECK();
     return CMP_OK;
@@ -1740,8 +1807,11 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
     }
     const double fl = (double)B * H * (double)Tn * Tn * D;        // one product over the unmasked half
     PROF_START(4, s);
-    if (d.thr) attn_dq_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
-    else attn_dq_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+    static const int wgs_per_cu = attn_wgs_per_cu(attn_dq_kernel<T, D, true>, smem);
+    const int plan_u = attn_plan_u(Tn, B * H, wgs_per_cu);
+    const dim3 qgrid = attn_plan_grid(Tn, B * H, plan_u);
+    if (d.thr) attn_dq_kernel<T, D, true><<<qgrid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d, plan_u);
+    else attn_dq_kernel<T, D, false><<<qgrid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d, plan_u);
     PROF_STOP(4, s, 3.0 * fl, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));       // q, k, v, o, dO, lse in; dQ, delta out
     KERNEL_CHECK();
     PROF_START(5, s);

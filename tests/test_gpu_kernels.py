@@ -396,15 +396,11 @@ def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
         assert rel_err(dqkv[:, sl], ref[:, sl]) < tol * 2, name
 
 
-@pytest.mark.parametrize("dtype,T,p", [(BF16, 1024, 0.0), (BF16, 1024, 0.1), (BF16, 2048, 0.0), (BF16, 2048, 0.1), (FP32, 1024, 0.1)])
-def test_attention_full_length_many_groups(lib, dtype, T, p):
-    """BASELINE shapes (seq 1024 / 2048, D = 64) with B*H = 64 (batch, head) groups: the balanced q-block pairing, the XCD
-    re-deal of workgroups and the 64-key fused softmax step run with >= 8 query blocks per group.  The whole grid runs on the
-    GPU; the float64 reference is computed for five (batch, head) groups (first, last and three in between), each of them
+def check_attention_groups(lib, B, H, D, T, dtype, p, groups):
+    """The whole grid runs on the GPU; the float64 reference is computed for the listed (batch, head) groups, each of them
     checked in full: o, lse, dq, dk, dv."""
-    B, H, D = 8, 8, 64
     E = H * D
-    g = torch.Generator().manual_seed(T + int(p * 100) + dtype)
+    g = torch.Generator().manual_seed(T + int(p * 100) + dtype + B)
     qkv = dev(torch.randn(B * T, 3 * E, generator=g), dtype)
     do = dev(torch.randn(B * T, E, generator=g), dtype)
     o = torch.zeros(B * T, E, device="cuda", dtype=tdt(dtype))
@@ -419,9 +415,14 @@ def test_attention_full_length_many_groups(lib, dtype, T, p):
     dh = do.double().cpu().reshape(B, T, H, D)
     gh = dqkv.double().cpu().reshape(B, T, 3, H, D)
     lh = lse.cpu().reshape(B, H, T)
+    # no 128-position block of any (batch, head) group left at its zero initialisation: every block was visited by both launches
+    # (single positions can be exactly zero: dq of position 0, dv of a position whose probabilities were all dropped)
+    for t0 in range(0, T, 128):
+        assert bool((oh[:, t0:t0 + 128] != 0).any(-1).any(1).all()) and bool((lh[:, :, t0:t0 + 128] != 0).any(-1).all()), t0
+        assert bool((gh[:, t0:t0 + 128] != 0).any(-1).any(1).all()), t0
     tol = TOL[dtype] * (3 if dtype == BF16 else 1)
     tri = torch.tril(torch.ones(T, T, dtype=torch.float64))
-    for b, h in ((0, 0), (1, 5), (3, 2), (6, 7), (7, 7)):
+    for b, h in groups:
         x = qh[b, :, :, h, :].clone().requires_grad_(True)          # [T, 3, D]
         w = (x[:, 0] @ x[:, 1].T) * (1.0 / math.sqrt(D))
         w = w * tri - 1e4 * (1 - tri)
@@ -435,6 +436,31 @@ def test_attention_full_length_many_groups(lib, dtype, T, p):
         assert rel_err(lh[b, h], torch.logsumexp(w, -1).detach()) < (1e-5 if dtype == FP32 else 2e-2), (b, h)
         for j, name in enumerate(("dq", "dk", "dv")):
             assert rel_err(gh[b, :, j, h, :], x.grad[:, j]) < tol * 2, (b, h, name)
+
+
+@pytest.mark.parametrize("dtype,T,p", [(BF16, 1024, 0.0), (BF16, 1024, 0.1), (BF16, 2048, 0.0), (BF16, 2048, 0.1), (FP32, 1024, 0.1)])
+def test_attention_full_length_many_groups(lib, dtype, T, p):
+    """BASELINE shapes (seq 1024 / 2048, D = 64) with B*H = 64 (batch, head) groups: the balanced q-block pairing, the XCD
+    re-deal of workgroups and the 64-key fused softmax step run with >= 8 query blocks per group; five groups (first, last and
+    three in between) against float64."""
+    check_attention_groups(lib, 8, 8, 64, T, dtype, p, ((0, 0), (1, 5), (3, 2), (6, 7), (7, 7)))
+
+
+@pytest.mark.parametrize("dtype,B,H,D,T,p", [
+    (BF16, 32, 8, 64, 1024, 0.1),      # 32 rows per XCD, 128 pairs over 96 slots: 24 rows paired, 8 as single blocks
+    (BF16, 16, 8, 64, 1000, 0.1),      # less than one round of pairs: 12 of 16 rows as single blocks; ragged last block
+    (BF16, 40, 8, 64, 640, 0.0),       # five blocks per row (the middle one runs alone in a paired row), 8 rows unpaired
+    (BF16, 8, 16, 32, 2048, 0.1),      # 16 blocks per row, head size 32
+    (FP32, 40, 8, 64, 512, 0.1),       # parity mode: two workgroups per CU, 64 slots per XCD
+])
+def test_attention_block_plans(lib, dtype, B, H, D, T, p):
+    """Forward and dQ launches whose paired workgroups do not fill whole rounds of the resident slots run the rows of the last
+    round as single blocks, heaviest first (attention.hip attn_job / attn_plan_u): every block of every row must still be
+    computed exactly once.  Groups from the paired part and from the unpaired part (row index within an XCD below the plan's
+    count) against float64, and the whole output must be free of untouched (zero-initialised) rows."""
+    rows = B * H
+    groups = sorted({(0, 0), (0, H - 1), ((rows // 2) // H, (rows // 2) % H), ((rows - 9) // H, (rows - 9) % H), (B - 1, H - 1)})
+    check_attention_groups(lib, B, H, D, T, dtype, p, groups)
 
 
 def test_attention_forced_rescale(lib):
