@@ -889,7 +889,16 @@ extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gam
     return CMP_OK;
 }
 
-static int ln_bwd_grid(int rows) { return std::max(1, std::min(cdiv(rows, 8), 2048)); }
+// workgroups of the backward launch: 8 rows per workgroup up to a cap.  Every workgroup leaves 3E partial sums for
+// ln_param_reduce_kernel, so the cap also sets that traffic: same-box whole-step A/B, cap 512 / 1024 / 2048 / 4096:
+// 7.40 / 7.38 / 7.45 / 7.57 ms at 32768 rows (C2, B=32), 26.70 / 26.54 / 26.54 / 26.69 ms at 131072 rows.
+static int ln_bwd_grid(int rows) {
+    int cap = 1024;
+#ifdef COMPOSER_EXPERIMENTS
+    if (const char* e = getenv("COMPOSER_LN_BWD_GRID")) cap = atoi(e);
+#endif
+    return std::max(1, std::min(cdiv(rows, 8), cap));
+}
 
 extern "C" int64_t cmp_k_layernorm_bwd_ws(int rows, int E) { return (int64_t)ln_bwd_grid(rows) * 3 * E * sizeof(float); }
 
