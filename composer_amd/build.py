@@ -24,6 +24,14 @@ ROOT = os.path.dirname(HERE)
 SOURCES = ["elementwise.hip", "gemm.hip", "attention.hip", "model.hip", "decode.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-inline-asm", "-I" + os.path.join(ROOT, "include")]
+# per-source additions.  attention.hip: without SLP vectorisation -- hipcc packs neighbouring f32 multiplies / adds of the softmax
+# into v_pk_*_f32, which cost more issue time beside MFMAs than the scalar pairs they replace (MI355X_MICROARCH.md, "packed f32
+# VALU ... an anti-lever beside MFMAs"); whole-step A/B: C2 26.47 -> 26.32 ms, B=32 7.43 -> 7.40, C4 56.04 -> 55.68.
+SOURCE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+
+
+def flags_for(src, flags=None):
+    return list(FLAGS if flags is None else flags) + SOURCE_FLAGS.get(src, [])
 
 
 def _hipcc():
@@ -105,7 +113,7 @@ def build(force=False, verbose=True, asan=False):
     lib = os.path.join(LIBDIR, "libcomposer_hip_asan.so") if asan else LIB
     info_path = os.path.join(LIBDIR, "BUILD_INFO_asan.json" if asan else "BUILD_INFO.json")
     with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
-        res = list(ex.map(lambda s: _compile(s, force, flags, tag), SOURCES))
+        res = list(ex.map(lambda s: _compile(s, force, flags_for(s, flags), tag), SOURCES))
     objs = [o for o, _, _ in res]
     lib_key = _lib_key([k for _, _, k in res])
     old = {}
@@ -141,7 +149,7 @@ def verify():
         return False
     if not os.path.exists(LIB):
         return False
-    want = _lib_key([source_key(s, FLAGS) for s in SOURCES])
+    want = _lib_key([source_key(s, flags_for(s)) for s in SOURCES])
     if info.get("library_key") != want or info.get("library_sha256") != _file_sha256(LIB):
         return False
     # ... and the key linked INTO the library (a replaced or older .so next to a fresh BUILD_INFO.json fails here)

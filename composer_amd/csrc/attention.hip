@@ -246,21 +246,20 @@ __device__ __forceinline__ float max16(const f32x16& s) {
     return max3(max3(a, b, c), max3(d, e, s[15]), a);
 }
 
-// Packed-f32 forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 process two values per lane-instruction): the softmax
-// loops are VALU-bound (D = 64: ~4 vector cycles per MFMA cycle), and hipcc leaves these element loops scalar.
-__device__ __forceinline__ f32x2 pair_of(const f32x16& v, int r) { return f32x2{v[r], v[r + 1]}; }
-// p = exp2(s * c - m) on all 16 values; returns the sum of the results as two partial sums
+// p = exp2(s * c - m) on all 16 values; returns the sum of the results as two partial sums.  Scalar fma / exp / add on purpose
+// (and attention.hip is compiled without SLP vectorisation, build.py): the packed forms v_pk_fma_f32 / v_pk_add_f32 process two
+// values per instruction but cost more issue time beside MFMAs than the two scalar instructions (whole-step A/B in build.py).
 __device__ __forceinline__ f32x2 exp2_scaled16(f32x16& s, float c, float negm, f32x2 sum) {
-    const f32x2 cv = {c, c}, mv = {negm, negm};
+    float s0 = sum[0], s1 = sum[1];
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        const f32x2 a = __builtin_elementwise_fma(pair_of(s, r), cv, mv);
-        const f32x2 p = {fast_exp2(a[0]), fast_exp2(a[1])};
-        sum += p;
-        s[r] = p[0];
-        s[r + 1] = p[1];
+        const float p0 = fast_exp2(fmaf(s[r], c, negm)), p1 = fast_exp2(fmaf(s[r + 1], c, negm));
+        s0 += p0;
+        s1 += p1;
+        s[r] = p0;
+        s[r + 1] = p1;
     }
-    return sum;
+    return f32x2{s0, s1};
 }
 // Keeps hipcc from sinking a select below the bf16 conversion: it rewrites cvt(select(c, p, 0)) as
 // select(c, cvt(p), 0), which turns 8 two-value v_cvt_pk_bf16_f32 into 16 single conversions plus 8 v_perm_b32.

@@ -16,7 +16,7 @@ def main():
     built = {}
     for src in srcs:
         built[src] = os.path.join(B.OBJ, "ab_%s_%s" % (name, src.replace(".hip", ".o")))
-        subprocess.run([B._hipcc()] + B.FLAGS + extra + ["-c", os.path.join(B.CSRC, src), "-o", built[src]], check=True)
+        subprocess.run([B._hipcc()] + B.flags_for(src) + extra + ["-c", os.path.join(B.CSRC, src), "-o", built[src]], check=True)
     objs = [built.get(s, os.path.join(B.OBJ, s.replace(".hip", ".o"))) for s in B.SOURCES] + [os.path.join(B.OBJ, "buildkey.o")]
     out = os.path.join(B.LIBDIR, name + ".so")
     subprocess.run([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs +
