@@ -294,6 +294,31 @@ __device__ __forceinline__ void mask16_qlane(f32x16& v, uint32_t rowh, int k0, i
 template <typename T, int D>
 __device__ __forceinline__ void store_t_tile(T* __restrict__ out, int64_t ostride, int row, bool valid, int dt,
                                              const f32x16& y, float mul, int h) {
+    if constexpr (std::is_same<T, bf16_t>::value && D % 32 == 0) {
+        // The two lanes of a row (l, l + 32) own alternating 8-byte groups of it.  One v_permlane32_swap per dword regroups them
+        // so that each lane holds 16 contiguous bytes: 2 dwordx4 stores per tile and lane instead of 4 dwordx2 (the store tail of
+        // a block is store-ISSUE-bound, MI355X_MICROARCH.md "attention epilogue store tail").
+#pragma unroll
+        for (int gp = 0; gp < 4; gp += 2) {
+            uint32_t w[2][2];                  // [group gp | gp + 1][dword]: 4 bf16 each
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+                    const bf2 t = {(bf16_t)(y[4 * (gp + k) + 2 * j] * mul), (bf16_t)(y[4 * (gp + k) + 2 * j + 1] * mul)};
+                    w[k][j] = __builtin_bit_cast(uint32_t, t);
+                }
+            // swap lanes 32..63 of the first operand with lanes 0..31 of the second: afterwards lane l < 32 holds group gp of
+            // both halves (its own 4 values, then its partner's), lane l + 32 group gp + 1 of both halves
+#pragma unroll
+            for (int j = 0; j < 2; j++) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(w[0][j]), "+v"(w[1][j]));
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+            const u32x4 v = {w[0][0], w[0][1], w[1][0], w[1][1]};
+            if (valid) *reinterpret_cast<u32x4*>(out + (int64_t)row * ostride + 32 * dt + 8 * (gp + h)) = v;
+        }
+        return;
+    }
     if (!valid) return;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
