@@ -392,8 +392,12 @@ def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
     ref = x.grad.reshape(B * T, 3 * E)
     assert rel_err(bias_grad, ref.sum(0) + 2.0) < tol
     assert rel_err(delta, (do.double() * o.double()).reshape(B, T, H, D).sum(-1).permute(0, 2, 1).reshape(-1)) < tol
+    # per slice, relative to that slice's largest reference value -- but not to less than 1 % of the whole gradient's: at T = 1
+    # dq is exactly zero in exact arithmetic (p = 1, dp = delta) and the kernel's dp - delta is a rounding residue of o
+    whole = ref.abs().max().item()
     for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
-        assert rel_err(dqkv[:, sl], ref[:, sl]) < tol * 2, name
+        err = (dqkv[:, sl].double().cpu() - ref[:, sl]).abs().max().item()
+        assert err / max(ref[:, sl].abs().max().item(), 1e-2 * whole, 1e-30) < tol * 2, name
 
 
 def check_attention_groups(lib, B, H, D, T, dtype, p, groups):
