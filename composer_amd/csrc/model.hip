@@ -1198,6 +1198,36 @@ extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* hos
     return CMP_OK;
 }
 
+// all_hidden_states[index] of the LAST forward pass (Transformer.call with output_hidden_states, transformer.py:800-816): the
+// input of decoder block `index` for index < L (index 0 = the embedding sum after its dropout), the ln_f output for index = L.
+template <typename T_>
+__global__ void hidden_unpack_kernel(const T_* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = to_f32<T_>(in[i]);
+}
+extern "C" int cmp_hidden_get_at(cmp_model* m, int index, int B, int T, int64_t generation, float* host_out) {
+    CMP_REQUIRE(m && host_out, "hidden_get_at: null argument");
+    CMP_REQUIRE(index >= 0 && index <= m->L, "hidden_get_at: index %d outside [0, %d]", index, m->L);
+    CMP_REQUIRE(generation == m->fwd_gen, "hidden_get_at: these hidden states belong to forward pass %lld, the activations held are "
+                "those of pass %lld (a later forward / train step / decode prefill overwrote them)",
+                (long long)generation, (long long)m->fwd_gen);
+    CMP_REQUIRE(B > 0 && T > 0 && !m->act.empty() && B == m->lastB && T == m->lastT - m->last_past,
+                "hidden_get_at: the forward pass held is [%d,%d] (batch, new positions), not [%d,%d]", m->lastB,
+                m->lastT - m->last_past, B, T);
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    const int64_t n = (int64_t)B * T * m->E;
+    const void* src = index < m->L ? m->xs[index] : m->hf;
+    float* tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
+    const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
+    if (m->dtype == CMP_BF16) hidden_unpack_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)src, tmp, n);
+    else hidden_unpack_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)src, tmp, n);
+    hipError_t e = hipMemcpyAsync(host_out, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, m->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(tmp);
+    HIP_CHECK(e);
+    return CMP_OK;
+}
+
 // host `past` [2, B, H, Tp, D] (fp32) -> K and V columns of rows [0, Tp) of qkv viewed as [B, Tt, 3E]; the Q columns of those
 // rows are zeroed (their attention outputs are never read)
 // (D: the head size the kernels run on, Dl <= D the reference's = the host tensor's; columns Dl..D-1 are zeroed)

@@ -66,8 +66,10 @@ class Transformer:
         if use_relative_attention:
             # the reference path is broken (Attention.build reads an undefined self.depth, transformer.py:285)
             raise NotImplementedError('use_relative_attention is not supported (broken in the reference too)')
-        if output_hidden_states or output_attention_weights:
-            raise NotImplementedError('output_hidden_states / output_attention_weights are never used by the CLI path')
+        if output_attention_weights:
+            raise NotImplementedError('output_attention_weights is never used by the CLI path (the [B,H,T,T] probabilities are '
+                                      'never materialised here)')
+        self.output_hidden_states = bool(output_hidden_states)
         self.vocab_size = vocab_size
         self.embedding_size = embedding_size
         self.window_size = window_size
@@ -253,7 +255,7 @@ class Transformer:
 
     def __call__(self, inputs, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
                  input_embeddings=None, use_cache=True, training=False):
-        """Transformer.call (transformer.py:696-833) -> (logits [B,T,V] float32, presents).
+        """Transformer.call (transformer.py:696-833) -> (logits [B,T,V] float32, presents[, all_hidden_states]).
 
         `past` = an earlier call's presents (L tensors [2,B,H,Tp,D], or the lazy Presents object): only the last input
         token is used (:735-737), it sits at position Tp (:760-770), its keys/values are appended to `past` (:423-426)
@@ -284,11 +286,21 @@ class Transformer:
         logits = np.empty((B, T, self.vocab_size), np.float32)
         _lib.check(self._lib.cmp_forward(self._h, x.ctypes.data_as(C.c_void_p), B, T, past_len, past_ptrs, int(bool(training)),
                                          logits.ctypes.data_as(C.c_void_p)), 'cmp_forward')
+        gen = C.c_int64()
+        _lib.check(self._lib.cmp_forward_generation(self._h, C.byref(gen)), 'cmp_forward_generation')
+        outputs = (logits,)
         if use_cache is True:
-            gen = C.c_int64()
-            _lib.check(self._lib.cmp_forward_generation(self._h, C.byref(gen)), 'cmp_forward_generation')
-            return logits, Presents(self, B, past_len + T, int(gen.value))
-        return (logits,)
+            outputs += (Presents(self, B, past_len + T, int(gen.value)),)
+        if self.output_hidden_states:
+            # transformer.py:800-816, 824-825: the input of every decoder block, then the ln_f output -- L + 1 tensors [B, T, E]
+            hidden = []
+            for i in range(self.decoder_layers_count + 1):
+                h = np.empty((B, T, self.embedding_size), np.float32)
+                _lib.check(self._lib.cmp_hidden_get_at(self._h, i, B, T, int(gen.value), h.ctypes.data_as(C.c_void_p)),
+                           'cmp_hidden_get_at')
+                hidden.append(h)
+            outputs += (tuple(hidden),)
+        return outputs
 
     def _fetch_present(self, layer, B, T, generation):
         """presents[layer] = stack([key, value]) [2,B,H,T,D] of the forward pass that produced this Presents object.  Valid

@@ -164,6 +164,10 @@ int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out);
  * so a stale read must be an error, never another pass's keys/values. */
 int cmp_forward_generation(cmp_model* m, int64_t* generation);
 int cmp_present_get_at(cmp_model* m, int layer, int B, int T, int64_t generation, float* host_out);
+/* all_hidden_states[index] of the forward pass `generation` (Transformer(..., output_hidden_states=True), transformer.py:610-614,
+ * 800-816, 824-825): host fp32 [B, T, E] -- the input of decoder block `index` for index < L (index 0 = token + position
+ * embedding after the embedding dropout), the ln_f output for index = L.  T = the pass's NEW positions (1 with `past`). */
+int cmp_hidden_get_at(cmp_model* m, int index, int B, int T, int64_t generation, float* host_out);
 
 /* ---- decode: the loop of cli.py:659-676 -------------------------------------------------------
  * temperature <= 0 => argmax with lowest-index tie-break (the tau->0 limit; cli.py:671 divides). */

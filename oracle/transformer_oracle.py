@@ -233,12 +233,13 @@ class OracleTransformer:
         h = P["wte/weight"][x] + P["wpe/embeddings"][pos][None]      # :137-138,786,793
         h, m_emb = self._dropout(h, c.p_resid, step, 0, 0, training)  # :794
         h = R(h)
-        cache = {"x": x, "pos": pos, "m_emb": m_emb, "layers": []}
+        cache = {"x": x, "pos": pos, "m_emb": m_emb, "layers": [], "hidden": []}
         presents = []
         for i in range(c.L):
             pre = "decoder_blocks/%d/" % i
             lc = {}
             x_in = h
+            cache["hidden"].append(h)                                 # all_hidden_states :800-802
             # DecoderBlock.call :574-597 -- NOTE ln_1 output OVERWRITES the residual stream (:583-587)
             if c.use_ln:
                 u, lc["ln1"] = layernorm_fwd(x_in, P[pre + "ln_1/gamma"], P[pre + "ln_1/beta"], c.eps)
@@ -299,6 +300,7 @@ class OracleTransformer:
         hf = R(hf)
         logits = hf @ Wt("wte/weight").T                              # :139-144,818
         cache["hf"], cache["lnf"] = hf, lnf
+        cache["hidden"].append(hf)                                    # ... and the last hidden state :814-816
         return logits, presents, cache
 
     # ---------------------------------------------------------------- loss

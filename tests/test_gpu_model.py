@@ -299,6 +299,40 @@ def test_call_with_past_matches_oracle():
     m.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+def test_output_hidden_states_match_the_oracle(dtype, tol):
+    """Transformer(..., output_hidden_states=True) (transformer.py:610-614, 800-816, 824-825): the call returns a third element,
+    the input of every decoder block followed by the ln_f output -- L + 1 tensors [B, T, E]; with `past` they cover the one new
+    position; with use_cache=False the tuple is (logits, hidden states)."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W, T, B = 390, 64, 4, 3, 48, 40, 2
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=5, stddev=0.1).items()}
+    x, _ = O.synthetic_batch(np.random.default_rng(3), V, B, T)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), {k: v.astype(np.float64) for k, v in params.items()},
+                              emulate_bf16=(dtype == "bf16"))
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, output_hidden_states=True, dtype=dtype,
+                    max_batch=B, max_seq=W)
+    m.set_weights(params)
+
+    def check(hidden, cache, t):
+        assert len(hidden) == L + 1
+        for i, (got, want) in enumerate(zip(hidden, cache["hidden"])):
+            assert got.shape == (B, t, E) and got.dtype == np.float32
+            assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), i
+
+    logits, pres, hidden = m(x[:, :30])
+    olg, opast, cache = orc.forward(x[:, :30])
+    check(hidden, cache, 30)
+    logits, pres, hidden = m(x[:, :31], past=pres)                    # one new position
+    olg, opast, cache = orc.forward(x[:, 30:31], past=opast)
+    check(hidden, cache, 1)
+    out = m(x, use_cache=False)
+    assert len(out) == 2 and len(out[1]) == L + 1 and out[1][0].shape == (B, T, E)
+    m.close()
+    with pytest.raises(NotImplementedError):
+        Transformer(V, E, W, L, H, output_attention_weights=True, dtype=dtype, max_batch=B, max_seq=W)
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
 def test_call_training_true_applies_the_train_step_dropout(dtype, tol):
     """self(x, training=True) (transformer.py:916-917): logits with dropout on, masks = the shared counter hash at the current
