@@ -71,6 +71,7 @@ SIGNATURES = {
     "cmp_hidden_get_at": (_i, [_P, _i, _i, _i, _i64, _P]),
     "cmp_forward_logits": (_i, [_P, _P, _i, _i, _P]),
     "cmp_forward": (_i, [_P, _P, _i, _i, _i, _P, _i, _P]),
+    "cmp_forward_ex": (_i, [_P, _P, _i, _i, _i, _P, _i, _P, _P, _P]),
     "cmp_decode_begin": (_i, [_P, _P, _i, _i, _f, _u64]),
     "cmp_decode_steps": (_i, [_P, _i, _P]),
     "cmp_k_sample": (_i, [_P, _P, _i, _f, _u64, _u32, _i, _P]),
@@ -101,7 +102,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
+_ADDED_LATER = {"cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
 
 _lib = None
 

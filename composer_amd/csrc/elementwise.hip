@@ -7,10 +7,13 @@
 // =================================================================================================
 // Embedding: h[b,t,:] = wte[x[b,t],:] + wpe[pos0+t,:]  (+ dropout)      transformer.py:137-138,786,793-794
 // =================================================================================================
+// pos_ids / type_ids (per token, or null): Transformer.call's position_ids (:770-773, 786) and token_type_ids (:787-791:
+// a second row of wte added to the sum) -- forward passes only; the train loop never passes them (:916-917)
 template <typename T>
 __global__ void embed_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ wte,
                                  const float* __restrict__ wpe, T* __restrict__ out, int ntok, int T_,
-                                 int E, int pos0, DropCfg drop) {
+                                 int E, int pos0, DropCfg drop, const int32_t* __restrict__ pos_ids,
+                                 const int32_t* __restrict__ type_ids) {
     constexpr int VN = Vec16<T>::N;
     const int chunks = E / VN;
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -21,16 +24,19 @@ __global__ void embed_fwd_kernel(const int32_t* __restrict__ ids, const float* _
         int id = ids[tok];
         int t = tok % T_;
         const float* a = wte + (int64_t)id * E + e0;
-        const float* p = wpe + (int64_t)(pos0 + t) * E + e0;
+        const float* p = wpe + (int64_t)(pos_ids ? pos_ids[tok] : pos0 + t) * E + e0;
+        const float* ty = type_ids ? wte + (int64_t)type_ids[tok] * E + e0 : nullptr;
         Vec16<T> r;
         const uint32_t rowh = drop_row_hash(drop, (uint32_t)tok);
 #pragma unroll
         for (int i = 0; i < VN; i += 4) {
             f32x4 av = *reinterpret_cast<const f32x4*>(a + i);
             f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+            f32x4 tv = {0.f, 0.f, 0.f, 0.f};
+            if (ty) tv = *reinterpret_cast<const f32x4*>(ty + i);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float v = av[j] + pv[j];
+                float v = ty ? (av[j] + pv[j]) + tv[j] : av[j] + pv[j];        // :793 input + position + token-type
                 if (drop.thr) v = apply_drop_rc(drop, rowh, (uint32_t)(e0 + i + j), v);
                 r.set(i + j, v);
             }
@@ -761,6 +767,11 @@ __global__ void colsum_fold_kernel(const float* __restrict__ part, float* __rest
 extern "C" int cmp_k_embed_fwd(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out,
                                int B, int T, int E, int pos0, int dtype, float p_drop, uint64_t seed,
                                uint32_t rng_stream) {
+    return embed_fwd_run(stream, ids, wte, wpe, out, B, T, E, pos0, dtype, p_drop, seed, rng_stream, nullptr, nullptr);
+}
+
+int embed_fwd_run(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, int B, int T, int E, int pos0,
+                  int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, const int32_t* pos_ids, const int32_t* type_ids) {
     CMP_REQUIRE(E % 8 == 0, "embed_fwd: E=%d must be a multiple of 8", E);
     hipStream_t s = (hipStream_t)stream;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
@@ -769,11 +780,11 @@ extern "C" int cmp_k_embed_fwd(void* stream, const int32_t* ids, const float* wt
     if (dtype == CMP_BF16) {
         int64_t total = (int64_t)ntok * (E / 8);
         int grid = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-        embed_fwd_kernel<bf16_t><<<grid, 256, 0, s>>>(ids, wte, wpe, (bf16_t*)out, ntok, T, E, pos0, d);
+        embed_fwd_kernel<bf16_t><<<grid, 256, 0, s>>>(ids, wte, wpe, (bf16_t*)out, ntok, T, E, pos0, d, pos_ids, type_ids);
     } else {
         int64_t total = (int64_t)ntok * (E / 4);
         int grid = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-        embed_fwd_kernel<float><<<grid, 256, 0, s>>>(ids, wte, wpe, (float*)out, ntok, T, E, pos0, d);
+        embed_fwd_kernel<float><<<grid, 256, 0, s>>>(ids, wte, wpe, (float*)out, ntok, T, E, pos0, d, pos_ids, type_ids);
     }
     KERNEL_CHECK();
     return CMP_OK;

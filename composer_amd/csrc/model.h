@@ -103,6 +103,8 @@ struct cmp_model {
     int capB = 0, capT = 0;
     std::vector<void*> allocs;
     std::vector<void*> xs;     // L+1 residual-stream tensors
+    const int32_t* fwd_pos_ids = nullptr;      // cmp_forward_ex only: per-token position / token-type ids of the pass being run
+    const int32_t* fwd_type_ids = nullptr;
     std::vector<LayerAct> act;
     void *hf = nullptr, *dlogits = nullptr;
     float* logits_pack = nullptr;      // [tokens, V] contiguous copy of the logits for cmp_forward's host transfer (allocated on first use)
@@ -163,6 +165,8 @@ template <typename Tp> static int dev_alloc(cmp_model* m, Tp** p, size_t bytes) 
 }
 
 // elementwise.hip
+int embed_fwd_run(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, int B, int T, int E, int pos0,
+                  int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, const int32_t* pos_ids, const int32_t* type_ids);
 int embed_bwd_run(void* stream, const int32_t* ids, const void* dh, float* dwte, float* dwpe, int B, int T, int E, int pos0,
                   int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, int V, float* det_ws, size_t det_ws_bytes,
                   int sort_V = 0, int* sort_ws = nullptr, int64_t sort_ws_words = 0);

@@ -689,8 +689,8 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
     const int Tp = past_len, Tt = past_len + T;
     m->lastB = B; m->lastT = Tt; m->last_past = Tp;
     m->fwd_gen += 1;
-    CHECK_RC(cmp_k_embed_fwd(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, Tp, dt, pr, m->drop_seed(),
-                             drop_stream(step, 0, 0)));
+    CHECK_RC(embed_fwd_run(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, Tp, dt, pr, m->drop_seed(),
+                           drop_stream(step, 0, 0), m->fwd_pos_ids, m->fwd_type_ids));
     CHECK_RC(refresh_transposed_weights(m));
     // Conv1D weight operand of the forward GEMMs: [in,out] as stored (fp32 mode), or the transposed bf16 copy (tb = 1)
     const bool wt = m->ST != nullptr;
@@ -1261,6 +1261,12 @@ __global__ void logits_pack_kernel(const float* __restrict__ z, float* __restric
 
 extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                            float* logits_out) {
+    return cmp_forward_ex(m, x, B, T, past_len, past, training, nullptr, nullptr, logits_out);
+}
+
+// position_ids / token_type_ids: host int32 [B*T] or null (transformer.py:770-773, 786-793)
+extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
+                              const int32_t* position_ids, const int32_t* token_type_ids, float* logits_out) {
     CMP_REQUIRE(m && x && logits_out, "forward: null argument");
     CMP_REQUIRE(past_len >= 0 && (past_len == 0 || past != nullptr), "forward: past_len %d without past tensors", past_len);
     CMP_REQUIRE(T > 0 && T + past_len <= m->W, "forward: positions %d..%d exceed window_size %d (wpe rows, transformer.py:675-679,786)",
@@ -1268,6 +1274,29 @@ extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int pas
     HIP_CHECK(hipSetDevice(m->ctx->device));
     CHECK_RC(upload_xy(m, x, nullptr, B, T, past_len));
     hipStream_t s = m->ctx->stream;
+    // the optional id tensors ride in one device buffer that lives for this call
+    struct IdBuf {
+        cmp_model* m;
+        int32_t* dev = nullptr;
+        ~IdBuf() { m->fwd_pos_ids = m->fwd_type_ids = nullptr; if (dev) (void)hipFree(dev); }
+    } idbuf{m};
+    if (position_ids || token_type_ids) {
+        const int64_t n = (int64_t)B * T;
+        if (position_ids)
+            for (int64_t i = 0; i < n; i++)
+                CMP_REQUIRE(position_ids[i] >= 0 && position_ids[i] < m->W, "forward: position id %d at %lld outside the wpe table [0, %d)",
+                            position_ids[i], (long long)i, m->W);
+        if (token_type_ids) CHECK_RC(check_host_ids(m, token_type_ids, n, "token type ids"));
+        HIP_CHECK(hipMalloc((void**)&idbuf.dev, (size_t)n * 8));
+        if (position_ids) {
+            HIP_CHECK(hipMemcpyAsync(idbuf.dev, position_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+            m->fwd_pos_ids = idbuf.dev;
+        }
+        if (token_type_ids) {
+            HIP_CHECK(hipMemcpyAsync(idbuf.dev + n, token_type_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+            m->fwd_type_ids = idbuf.dev + n;
+        }
+    }
     if (past_len > 0) {
         const int64_t n = (int64_t)2 * B * m->H * past_len * m->Dl;         // the host tensors: [2, B, H, past_len, E / H]
         const int64_t ns = (int64_t)2 * B * m->H * past_len * m->D;        // K/V elements written (zero-padded heads included)

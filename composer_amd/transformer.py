@@ -262,8 +262,9 @@ class Transformer:
         and the returned presents hold Tp+1 positions.  `training=True` (:916-917) applies dropout with the masks a train
         step at the current optimizer iteration would draw; together with `past` the attention-probability mask is the new
         token's row of the mask over all Tp+1 positions."""
-        if attention_mask is not None or token_type_ids is not None or position_ids is not None or input_embeddings is not None:
-            raise NotImplementedError('attention_mask/token_type_ids/position_ids/input_embeddings are never used by the CLI path')
+        if attention_mask is not None or input_embeddings is not None:
+            # (input_embeddings cannot work in the reference either: transformer.py:758 casts inputs=None)
+            raise NotImplementedError('attention_mask / input_embeddings are never used by the CLI path')
         x = self._ids(inputs)
         past_len, past_ptrs, keep = 0, None, []
         if past is not None:
@@ -284,8 +285,21 @@ class Transformer:
             raise IndexError('position %d outside the wpe table (window_size %d, transformer.py:675-679,786)'
                              % (past_len + T - 1, self.window_size))
         logits = np.empty((B, T, self.vocab_size), np.float32)
-        _lib.check(self._lib.cmp_forward(self._h, x.ctypes.data_as(C.c_void_p), B, T, past_len, past_ptrs, int(bool(training)),
-                                         logits.ctypes.data_as(C.c_void_p)), 'cmp_forward')
+        pos = typ = None
+        if token_type_ids is not None:                                           # :787-791: a second wte row per token
+            typ = self._ids(token_type_ids)
+            if past is not None:
+                typ = typ[:, -1:]                                                # :741-742
+            typ = np.ascontiguousarray(np.broadcast_to(typ.reshape(-1, typ.shape[-1]), (B, T)))
+            self._check_ids(typ)
+        if position_ids is not None:                                             # :770-773, 784, 786: rows of wpe, [1,T] or [B,T]
+            pos = self._ids(position_ids)
+            pos = np.ascontiguousarray(np.broadcast_to(pos.reshape(-1, pos.shape[-1]), (B, T)))
+            if pos.size and (pos.min() < 0 or pos.max() >= self.window_size):
+                raise IndexError('position id outside the wpe table (window_size %d, transformer.py:675-679,786)' % self.window_size)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.cmp_forward_ex(self._h, x.ctypes.data_as(C.c_void_p), B, T, past_len, past_ptrs, int(bool(training)),
+                                            ptr(pos), ptr(typ), logits.ctypes.data_as(C.c_void_p)), 'cmp_forward_ex')
         gen = C.c_int64()
         _lib.check(self._lib.cmp_forward_generation(self._h, C.byref(gen)), 'cmp_forward_generation')
         outputs = (logits,)

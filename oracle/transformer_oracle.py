@@ -216,24 +216,33 @@ class OracleTransformer:
         m = keep.astype(self.dtype) * scale
         return x * m, m
 
-    def forward(self, x, past=None, training=False, step=0, keep_cache=False):
+    def forward(self, x, past=None, training=False, step=0, keep_cache=False, position_ids=None, token_type_ids=None):
         """Transformer.call (transformer.py:696-833).  x int [B,T].  past: list of L arrays
         [2,B,H,Tp,D] or None.  Returns logits [B,T,V], presents (list of [2,B,H,Tk,D]), cache."""
         c, P = self.cfg, self.p
         x = np.asarray(x)
         if past is not None:
             x = x[:, -1:]                                            # :735-737
+            if token_type_ids is not None:
+                token_type_ids = np.asarray(token_type_ids)[:, -1:]  # :741-742
         x = x.astype(np.int64)                                       # :758
         B, T = x.shape
         past_len = 0 if past is None else past[0].shape[-2]          # :760-765
-        pos = np.arange(past_len, T + past_len)                      # :770
+        if position_ids is None:
+            pos = np.arange(past_len, T + past_len)[None]            # :770-773
+        else:
+            pos = np.asarray(position_ids).astype(np.int64)
+            pos = pos.reshape(-1, pos.shape[-1])                     # :784
         if pos.max() >= c.W:
             raise IndexError("position %d outside wpe table (%d rows)" % (pos.max(), c.W))
         R, Wt = self.R, self._w
-        h = P["wte/weight"][x] + P["wpe/embeddings"][pos][None]      # :137-138,786,793
+        h = P["wte/weight"][x] + P["wpe/embeddings"][pos]            # :137-138,786,793
+        if token_type_ids is not None:                               # :787-793
+            tt = np.asarray(token_type_ids).astype(np.int64)
+            h = h + P["wte/weight"][tt.reshape(-1, tt.shape[-1])]
         h, m_emb = self._dropout(h, c.p_resid, step, 0, 0, training)  # :794
         h = R(h)
-        cache = {"x": x, "pos": pos, "m_emb": m_emb, "layers": [], "hidden": []}
+        cache = {"x": x, "pos": pos[0] if position_ids is None else pos, "m_emb": m_emb, "layers": [], "hidden": []}
         presents = []
         for i in range(c.L):
             pre = "decoder_blocks/%d/" % i

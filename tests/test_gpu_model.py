@@ -334,6 +334,45 @@ def test_output_hidden_states_match_the_oracle(dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_position_ids_and_token_type_ids_match_the_oracle(dtype, tol):
+    """Transformer.call(position_ids=, token_type_ids=) (transformer.py:770-773, 784-793): wpe rows chosen per token ([1,T]
+    broadcast over the batch, or [B,T]) and a second wte row added to every token's embedding; with `past` the last
+    token-type id is used (:741-742)."""
+    V, E, H, L, W, T, B = 390, 64, 4, 2, 48, 24, 3
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=6, stddev=0.1).items()}
+    rng = np.random.default_rng(4)
+    x, _ = O.synthetic_batch(rng, V, B, T)
+    orc = O.OracleTransformer(O.Config(V, E, W, L, H), {k: v.astype(np.float64) for k, v in params.items()},
+                              emulate_bf16=(dtype == "bf16"))
+    m = make_model((V, E, H, L, W, T, B), params, dtype)
+    close = lambda a, b: np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+    pos_row = rng.permutation(W)[:T][None].astype(np.int32)                     # [1, T]: shared by the batch
+    pos_all = rng.integers(0, W, size=(B, T)).astype(np.int32)                  # [B, T]
+    typ = rng.integers(0, 2, size=(B, T)).astype(np.int32)
+    base, _ = m(x)
+    for kw in (dict(position_ids=pos_row), dict(position_ids=pos_all), dict(token_type_ids=typ),
+               dict(position_ids=pos_all, token_type_ids=typ)):
+        got, pres = m(x, **kw)
+        want, opast, _ = orc.forward(x, **kw)
+        assert close(got, want), sorted(kw)
+        assert not close(got, base)                                            # ... and the ids do change the result
+    # one more token on top of the last call's presents: its own position id, the last token-type id
+    got, _ = m(np.concatenate([x, x[:, :1]], 1), past=pres, position_ids=np.full((B, 1), 5, np.int32),
+               token_type_ids=np.concatenate([typ, 1 - typ[:, :1]], 1))
+    want, _, _ = orc.forward(x[:, :1], past=opast, position_ids=np.full((B, 1), 5), token_type_ids=np.concatenate([typ, 1 - typ[:, :1]], 1))
+    assert close(got, want)
+    again, _ = m(x)
+    assert np.array_equal(again, base)                                         # the ids do not stick to the model
+    with pytest.raises(IndexError):
+        m(x, position_ids=np.full((1, T), W, np.int32))
+    with pytest.raises(Exception):
+        m(x, token_type_ids=np.full((B, T), V, np.int32))
+    with pytest.raises(NotImplementedError):
+        m(x, attention_mask=np.ones((B, T), np.int32))
+    m.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
 def test_call_training_true_applies_the_train_step_dropout(dtype, tol):
     """self(x, training=True) (transformer.py:916-917): logits with dropout on, masks = the shared counter hash at the current
     optimizer iteration, against the oracle's forward(training=True)."""
