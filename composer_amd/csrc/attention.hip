@@ -454,10 +454,13 @@ __device__ __forceinline__ void attn_job(int plan_u, int nb, int H, int& by, int
 // =================================================================================================
 // forward.  grid ((nb+1)/2, B*H), 256 threads: wave w owns query rows [qb*128 + 32w, +32)
 // =================================================================================================
-template <typename T, int D, bool DROP>
+// AMASK: Transformer.call's attention_mask (transformer.py:774-779, 356-358): amask[b][key] = (1 - mask) * -1e4 is ADDED to the
+// scaled, causally masked scores of every query of batch row b (forward passes only; the train loop never passes a mask).
+template <typename T, int D, bool DROP, bool AMASK = false>
 __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
                                                                           float* __restrict__ lse, int Tn, int H,
-                                                                          float scale, DropCfg drop, int plan_u) {
+                                                                          float scale, DropCfg drop, int plan_u,
+                                                                          const float* __restrict__ amask) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -480,6 +483,8 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     const T* vg = qg + 2 * E;
     T* og = o + (int64_t)b * Tn * E + hd * D;
     const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const float* am = AMASK ? amask + (int64_t)b * Tn : nullptr;
+    const float inv_scale = 1.0f / scale;           // throughput mode works on raw scores: the mask term goes in divided by the scale
 
     for (int ph = 0; ph < 2; ph++) {
         const int qb = ph == 0 ? qb0 : qb1;
@@ -495,7 +500,10 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
         float m = -INFINITY, lsum = 0.f;   // running max: scaled domain (parity mode) / raw domain (throughput mode)
-        const int kv_end = min(Tn, qb * 128 + 128);
+        // With a mask term no key tile is skipped: a causally masked key sits at -1e4 + its mask term, and in a row whose allowed
+        // keys are all masked out (a padding query) that is not negligible against the row maximum -- the reference's softmax
+        // runs over all of them (transformer.py:351-360).
+        const int kv_end = AMASK ? Tn : min(Tn, qb * 128 + 128);
         const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
 
         Stager<T, D> sk, sv;
@@ -541,6 +549,13 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
                 s0 = mma_rows<T, D>(Ks, 0, qf, lane, s0);
                 s1 = mma_rows<T, D>(Ks, 32, qf, lane, s1);
 #endif
+                if constexpr (AMASK) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        s0[r] += am[kt0 + rho(r, h)] * inv_scale;
+                        s1[r] += am[kt0 + 32 + rho(r, h)] * inv_scale;
+                    }
+                }
 #if ATTN_DIAG == 6
                 const float mloc = 0.f;
 #else
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
                 const int k0 = kt0 + 32 * sub;
-                if (k0 > q0w + 31 || k0 >= Tn) continue;          // wave-uniform: tile entirely masked
+                if ((!AMASK && k0 > q0w + 31) || k0 >= Tn) continue;          // wave-uniform: tile entirely masked
                 f32x16 s;
 #pragma unroll
                 for (int r = 0; r < 16; r++) s[r] = 0.f;
@@ -597,6 +612,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
                         int key = k0 + rho(r, h);
                         float v = s[r] * scale;
                         if (key > q || key >= Tn) v = -1e4f;          // w*b - 1e4*(1-b), transformer.py:354
+                        if constexpr (AMASK) v = key < Tn ? v + am[key] : -INFINITY;     // :356-358; keys past the end do not exist
                         s[r] = v;
                         mloc = fmaxf(mloc, v);
                     }
@@ -625,6 +641,13 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
                         for (int r = 0; r < 16; r++) {
                             int key = k0 + rho(r, h);
                             if (key > q || key >= Tn) s[r] = neg_big;       // == -1e4 after scaling
+                        }
+                    }
+                    if constexpr (AMASK) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int key = k0 + rho(r, h);
+                            s[r] = key < Tn ? s[r] + am[key] * inv_scale : -INFINITY;
                         }
                     }
                     float mloc = max16(s);
@@ -1742,7 +1765,8 @@ static int attn64_mode() {
 }
 #endif
 template <typename T, int D>
-static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d) {
+static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d,
+                      const float* amask) {
 #ifdef COMPOSER_EXPERIMENTS
     if constexpr (std::is_same<T, bf16_t>::value && D == 64) {
         const int nb = cdiv(Tn, 256), pairs = (nb + 1) / 2;
@@ -1811,9 +1835,19 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
     const int plan_u = attn_plan_u(Tn, B * H, wgs_per_cu);
     const dim3 grid = attn_plan_grid(Tn, B * H, plan_u);
     const double flops = 2.0 * B * H * (double)Tn * Tn * D;      // QK^T + PV on the unmasked half
+    if (amask) {      // Transformer.call(attention_mask=...): the instances that add the per-key mask term
+        if (smem > 65536) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        }
+        if (d.thr) attn_fwd_kernel<T, D, true, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u, amask);
+        else attn_fwd_kernel<T, D, false, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u, amask);
+        KERNEL_CHECK();
+        return CMP_OK;
+    }
     PROF_START(3, s);
-    if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u);
-    else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u);
+    if (d.thr) attn_fwd_kernel<T, D, true><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u, nullptr);
+    else attn_fwd_kernel<T, D, false><<<grid, 256, smem, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, plan_u, nullptr);
     PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * D * sizeof(T) + 4.0));      // q, k, v in; o, lse out
     KERNEL_CHECK();
     return CMP_OK;
@@ -1858,17 +1892,18 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
 
 extern "C" int cmp_k_attn_fwd(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, int scale,
                               int dtype, float p_drop, uint64_t seed, uint32_t rng_stream) {
-    return attn_fwd_run(stream, qkv, o, lse, B, T, H, D, scale ? 1.0f / sqrtf((float)D) : 1.0f, dtype, p_drop, seed, rng_stream);
+    return attn_fwd_run(stream, qkv, o, lse, B, T, H, D, scale ? 1.0f / sqrtf((float)D) : 1.0f, dtype, p_drop, seed, rng_stream, nullptr);
 }
 
 // sc: the factor on q.k (the model driver passes 1/sqrt(E/H) of the reference's head size, which may be smaller than D: zero-padded heads)
+// amask: device float [B, T] added to the scaled scores of every query of a batch row (null: none)
 int attn_fwd_run(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, float sc, int dtype, float p_drop,
-                 uint64_t seed, uint32_t rng_stream) {
+                 uint64_t seed, uint32_t rng_stream, const float* amask) {
     if (B * T == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
-    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
-    else { DISPATCH_D(float, launch_fwd, s, qkv, o, lse, B, T, H, sc, d) }
+    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_fwd, s, qkv, o, lse, B, T, H, sc, d, amask) }
+    else { DISPATCH_D(float, launch_fwd, s, qkv, o, lse, B, T, H, sc, d, amask) }
 }
 
 // One-shot for the kernel-level tests that call cmp_k_attn_bwd directly (per calling thread): the next cmp_k_attn_bwd also

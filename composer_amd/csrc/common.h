@@ -94,7 +94,7 @@ int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, 
                  int B, int T, int H, int D, float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
                  float* bias_grad);
 int attn_fwd_run(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, float sc, int dtype, float p_drop,
-                 uint64_t seed, uint32_t rng_stream);
+                 uint64_t seed, uint32_t rng_stream, const float* amask = nullptr);
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

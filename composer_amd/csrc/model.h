@@ -105,6 +105,7 @@ struct cmp_model {
     std::vector<void*> xs;     // L+1 residual-stream tensors
     const int32_t* fwd_pos_ids = nullptr;      // cmp_forward_ex only: per-token position / token-type ids of the pass being run
     const int32_t* fwd_type_ids = nullptr;
+    const float* fwd_amask = nullptr;          // ... and its additive attention mask term, float [B, past + T]
     std::vector<LayerAct> act;
     void *hf = nullptr, *dlogits = nullptr;
     float* logits_pack = nullptr;      // [tokens, V] contiguous copy of the logits for cmp_forward's host transfer (allocated on first use)

@@ -705,7 +705,7 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
                       nullptr, 0, nullptr, 0, 0, 1, 0.f, 0));
         if (Tp) CHECK_RC(rows_copy(m, m->dqkv, a.qkv, B, T, 3 * Ea, T, 0, 3 * Ea, Tt, Tp, 3 * Ea));  // concat([past, new]) :423-426
         CHECK_RC(attn_fwd_run(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, attn_scale(m), dt, pa, m->drop_seed(),
-                              drop_stream(step, i, 1)));
+                              drop_stream(step, i, 1), m->fwd_amask));
         const void* att = a.att;
         if (Tp) { CHECK_RC(rows_copy(m, a.att, m->tmpE, B, T, Ea, Tt, Tp, Ea, T, 0, Ea)); att = m->tmpE; }
         CHECK_RC(gemm(m, 0, wt, M, E, Ea, att, Ea, W(o.proj_w), wt ? Ea : E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
@@ -1261,12 +1261,20 @@ __global__ void logits_pack_kernel(const float* __restrict__ z, float* __restric
 
 extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                            float* logits_out) {
-    return cmp_forward_ex(m, x, B, T, past_len, past, training, nullptr, nullptr, logits_out);
+    return cmp_forward_ex(m, x, B, T, past_len, past, training, nullptr, nullptr, nullptr, logits_out);
 }
 
-// position_ids / token_type_ids: host int32 [B*T] or null (transformer.py:770-773, 786-793)
+// (1 - mask) * -10000 (transformer.py:774-779)
+__global__ void attention_mask_term_kernel(const int32_t* __restrict__ mask, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (1.0f - (float)mask[i]) * -10000.0f;
+}
+
+// position_ids / token_type_ids: host int32 [B*T] or null (transformer.py:770-773, 786-793); attention_mask: host int32
+// [B*(past_len+T)] or null (:774-779)
 extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
-                              const int32_t* position_ids, const int32_t* token_type_ids, float* logits_out) {
+                              const int32_t* position_ids, const int32_t* token_type_ids, const int32_t* attention_mask,
+                              float* logits_out) {
     CMP_REQUIRE(m && x && logits_out, "forward: null argument");
     CMP_REQUIRE(past_len >= 0 && (past_len == 0 || past != nullptr), "forward: past_len %d without past tensors", past_len);
     CMP_REQUIRE(T > 0 && T + past_len <= m->W, "forward: positions %d..%d exceed window_size %d (wpe rows, transformer.py:675-679,786)",
@@ -1278,16 +1286,16 @@ extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int 
     struct IdBuf {
         cmp_model* m;
         int32_t* dev = nullptr;
-        ~IdBuf() { m->fwd_pos_ids = m->fwd_type_ids = nullptr; if (dev) (void)hipFree(dev); }
+        ~IdBuf() { m->fwd_pos_ids = m->fwd_type_ids = nullptr; m->fwd_amask = nullptr; if (dev) (void)hipFree(dev); }
     } idbuf{m};
-    if (position_ids || token_type_ids) {
-        const int64_t n = (int64_t)B * T;
+    if (position_ids || token_type_ids || attention_mask) {
+        const int64_t n = (int64_t)B * T, nk = (int64_t)B * (past_len + T);
         if (position_ids)
             for (int64_t i = 0; i < n; i++)
                 CMP_REQUIRE(position_ids[i] >= 0 && position_ids[i] < m->W, "forward: position id %d at %lld outside the wpe table [0, %d)",
                             position_ids[i], (long long)i, m->W);
         if (token_type_ids) CHECK_RC(check_host_ids(m, token_type_ids, n, "token type ids"));
-        HIP_CHECK(hipMalloc((void**)&idbuf.dev, (size_t)n * 8));
+        HIP_CHECK(hipMalloc((void**)&idbuf.dev, (size_t)(2 * n + 2 * nk) * 4));
         if (position_ids) {
             HIP_CHECK(hipMemcpyAsync(idbuf.dev, position_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
             m->fwd_pos_ids = idbuf.dev;
@@ -1295,6 +1303,14 @@ extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int 
         if (token_type_ids) {
             HIP_CHECK(hipMemcpyAsync(idbuf.dev + n, token_type_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
             m->fwd_type_ids = idbuf.dev + n;
+        }
+        if (attention_mask) {
+            int32_t* raw = idbuf.dev + 2 * n;
+            float* term = reinterpret_cast<float*>(idbuf.dev + 2 * n + nk);
+            HIP_CHECK(hipMemcpyAsync(raw, attention_mask, (size_t)nk * 4, hipMemcpyHostToDevice, s));
+            attention_mask_term_kernel<<<(int)std::min<int64_t>(cdiv64(nk, 256), 1024), 256, 0, s>>>(raw, term, nk);
+            KERNEL_CHECK();
+            m->fwd_amask = term;
         }
     }
     if (past_len > 0) {

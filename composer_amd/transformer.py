@@ -262,9 +262,9 @@ class Transformer:
         and the returned presents hold Tp+1 positions.  `training=True` (:916-917) applies dropout with the masks a train
         step at the current optimizer iteration would draw; together with `past` the attention-probability mask is the new
         token's row of the mask over all Tp+1 positions."""
-        if attention_mask is not None or input_embeddings is not None:
-            # (input_embeddings cannot work in the reference either: transformer.py:758 casts inputs=None)
-            raise NotImplementedError('attention_mask / input_embeddings are never used by the CLI path')
+        if input_embeddings is not None:
+            # (it cannot work in the reference either: transformer.py:758 casts inputs=None)
+            raise NotImplementedError('input_embeddings is never used by the CLI path')
         x = self._ids(inputs)
         past_len, past_ptrs, keep = 0, None, []
         if past is not None:
@@ -297,9 +297,14 @@ class Transformer:
             pos = np.ascontiguousarray(np.broadcast_to(pos.reshape(-1, pos.shape[-1]), (B, T)))
             if pos.size and (pos.min() < 0 or pos.max() >= self.window_size):
                 raise IndexError('position id outside the wpe table (window_size %d, transformer.py:675-679,786)' % self.window_size)
+        amask = None
+        if attention_mask is not None:                                           # :774-779, 356-358: [B, past + new keys], 1 = attend
+            amask = np.ascontiguousarray(np.asarray(attention_mask).astype(np.int32))
+            if amask.shape != (B, past_len + T):
+                raise ValueError('attention_mask must be [batch, past_len + sequence] = %s; got %s' % ((B, past_len + T), amask.shape))
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         _lib.check(self._lib.cmp_forward_ex(self._h, x.ctypes.data_as(C.c_void_p), B, T, past_len, past_ptrs, int(bool(training)),
-                                            ptr(pos), ptr(typ), logits.ctypes.data_as(C.c_void_p)), 'cmp_forward_ex')
+                                            ptr(pos), ptr(typ), ptr(amask), logits.ctypes.data_as(C.c_void_p)), 'cmp_forward_ex')
         gen = C.c_int64()
         _lib.check(self._lib.cmp_forward_generation(self._h, C.byref(gen)), 'cmp_forward_generation')
         outputs = (logits,)

@@ -155,11 +155,14 @@ int cmp_forward_logits(cmp_model* m, const int32_t* x, int B, int T, float* logi
  *   mask over all past_len + T positions. */
 int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                 float* logits_out);
-/* ... with Transformer.call's position_ids and token_type_ids (transformer.py:770-773, 786-793): host int32 [B*T] each, or null.
+/* ... with Transformer.call's position_ids, token_type_ids (transformer.py:770-773, 786-793: host int32 [B*T] each, or null) and
+ * attention_mask (:774-779, 356-358: host int32 [B*(past_len+T)], 1 = attend, 0 = masked; or null).
  *   position_ids: the wpe row of every token (default past_len + t); token_type_ids: a second wte row added to every token's
- *   embedding.  Forward passes only (the reference's train loop passes neither, :916-917). */
+ *   embedding; attention_mask: (1 - mask) * -1e4 is added to the scaled, causally masked scores of every query of the batch
+ *   row, in every layer and head.  Forward passes only (the reference's train loop passes none of them, :916-917). */
 int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
-                   const int32_t* position_ids, const int32_t* token_type_ids, float* logits_out);
+                   const int32_t* position_ids, const int32_t* token_type_ids, const int32_t* attention_mask,
+                   float* logits_out);
 /* presents[layer] of the LAST forward pass (Transformer.call's second result, transformer.py:797-806, 820-821):
  * host fp32 [2, B, H, T, D] = stack([key, value]) after split_heads.  B, T must be that pass's shape (T = past + new). */
 int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out);

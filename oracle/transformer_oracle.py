@@ -216,7 +216,8 @@ class OracleTransformer:
         m = keep.astype(self.dtype) * scale
         return x * m, m
 
-    def forward(self, x, past=None, training=False, step=0, keep_cache=False, position_ids=None, token_type_ids=None):
+    def forward(self, x, past=None, training=False, step=0, keep_cache=False, position_ids=None, token_type_ids=None,
+                attention_mask=None):
         """Transformer.call (transformer.py:696-833).  x int [B,T].  past: list of L arrays
         [2,B,H,Tp,D] or None.  Returns logits [B,T,V], presents (list of [2,B,H,Tk,D]), cache."""
         c, P = self.cfg, self.p
@@ -271,6 +272,8 @@ class OracleTransformer:
             nd, ns = w.shape[-2:]
             b = causal_mask(nd, ns, self.dtype)[None, None]
             w = w * b - 1e4 * (1 - b)                                 # :351-354
+            if attention_mask is not None:                            # :774-779, 356-358
+                w = w + ((1.0 - np.asarray(attention_mask, dtype=self.dtype)) * -10000.0)[:, None, None, :]
             w = w - w.max(-1, keepdims=True)
             pun = np.exp(w)
             lsum = pun.sum(-1, keepdims=True)

@@ -368,7 +368,54 @@ def test_position_ids_and_token_type_ids_match_the_oracle(dtype, tol):
     with pytest.raises(Exception):
         m(x, token_type_ids=np.full((B, T), V, np.int32))
     with pytest.raises(NotImplementedError):
-        m(x, attention_mask=np.ones((B, T), np.int32))
+        m(x, input_embeddings=np.zeros((B, T, E), np.float32))
+    m.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("T", [24, 200])
+def test_attention_mask_matches_the_oracle(dtype, tol, T):
+    """Transformer.call(attention_mask=) (transformer.py:774-779, 356-358): (1 - mask) * -1e4 added to the scaled, causally masked
+    scores.  Right padding (every query keeps an unmasked key), scattered holes, left padding (the padding queries' allowed keys
+    are ALL masked: their softmax then runs over scores near -1e4, where the reference's fp32 sum has an ulp of 1e-3 -- those
+    positions are held to 5e-3 against the float64 oracle), dropout on, and one more token on top of `past`."""
+    V, E, H, L, W, B = 390, 64, 4, 2, 256, 3
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=8, stddev=0.1).items()}
+    rng = np.random.default_rng(5)
+    x, _ = O.synthetic_batch(rng, V, B, T)
+    ocfg = O.Config(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1)
+    orc = O.OracleTransformer(ocfg, {k: v.astype(np.float64) for k, v in params.items()}, seed=31, emulate_bf16=(dtype == "bf16"))
+    m = make_model((V, E, H, L, W, T, B), params, dtype, p_attn=0.1, p_resid=0.1, seed=31)
+    err = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    base, _ = m(x)
+    right = np.ones((B, T), np.int32)
+    for b in range(B):
+        right[b, T - 1 - 3 * b:] = 0 if b else 1
+    holes = (rng.random((B, T)) > 0.3).astype(np.int32)
+    holes[:, 0] = 1                                                             # key 0 stays: no fully masked row
+    for name, mask, training in (("right", right, False), ("holes", holes, False), ("holes", holes, True)):
+        got, pres = m(x, attention_mask=mask, training=training)
+        want, opast, _ = orc.forward(x, attention_mask=mask, training=training, step=0)
+        assert err(got, want) <= tol, (name, training)
+    assert err(got, base) > 0.2                                                 # ... and the mask does change the result
+    left = np.ones((B, T), np.int32)
+    left[1, :5] = 0                                                             # batch row 1: positions 0..4 are padding
+    got, _ = m(x, attention_mask=left)
+    want, _, _ = orc.forward(x, attention_mask=left)
+    keep = left.astype(bool)
+    assert err(got[keep], want[keep]) <= tol
+    assert err(got, want) <= max(tol, 5e-3)
+    # `past`: the mask covers the past keys and the new one
+    got, pres = m(x, attention_mask=holes)
+    want, opast, _ = orc.forward(x, attention_mask=holes)
+    more = np.concatenate([holes, np.ones((B, 1), np.int32)], 1)
+    got, _ = m(np.concatenate([x, x[:, :1]], 1), past=pres, attention_mask=more)
+    want, _, _ = orc.forward(x[:, :1], past=opast, attention_mask=more)
+    assert err(got, want) <= tol
+    again, _ = m(x)
+    assert np.array_equal(again, base)
+    with pytest.raises(ValueError):
+        m(x, attention_mask=np.ones((B, T + 1), np.int32))
     m.close()
 
 
