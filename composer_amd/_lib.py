@@ -71,7 +71,7 @@ SIGNATURES = {
     "cmp_hidden_get_at": (_i, [_P, _i, _i, _i, _i64, _P]),
     "cmp_forward_logits": (_i, [_P, _P, _i, _i, _P]),
     "cmp_forward": (_i, [_P, _P, _i, _i, _i, _P, _i, _P]),
-    "cmp_forward_ex": (_i, [_P, _P, _i, _i, _i, _P, _i, _P, _P, _P, _P]),
+    "cmp_forward_ex": (_i, [_P, _P, _i, _i, _i, _P, _i, _P, _P, _P, _P, _P]),
     "cmp_decode_begin": (_i, [_P, _P, _i, _i, _f, _u64]),
     "cmp_decode_steps": (_i, [_P, _i, _P]),
     "cmp_k_sample": (_i, [_P, _P, _i, _f, _u64, _u32, _i, _P]),

@@ -1906,6 +1906,46 @@ int attn_fwd_run(void* stream, const void* qkv, void* o, float* lse, int B, int 
     else { DISPATCH_D(float, launch_fwd, s, qkv, o, lse, B, T, H, sc, d, amask) }
 }
 
+// The attention probabilities themselves (Transformer(..., output_attention_weights=True), transformer.py:360-369, 808-809):
+// out[b][h][i - q0][j] = dropout(softmax row i)[j] for the queries i in [q0, Tn), recomputed from q, k and the forward
+// kernel's row log-sum-exp.  An inspection path (the [B,H,T,T] tensor the hot kernels never write): one workgroup per
+// (batch, head, query), a thread per key, plain dot products.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ qkv, const float* __restrict__ lse,
+                                                         const float* __restrict__ amask, float* __restrict__ out, int q0, int Tn,
+                                                         int H, int D, float scale, DropCfg drop) {
+    const int bh = blockIdx.y, i = q0 + blockIdx.x, b = bh / H, hd = bh % H;
+    const int E = H * D;
+    const int64_t rs = 3 * E;
+    const T* qrow = qkv + ((int64_t)b * Tn + i) * rs + hd * D;
+    const float l = lse[(int64_t)bh * Tn + i];
+    const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(bh * Tn + i));
+    float* orow = out + ((int64_t)bh * (Tn - q0) + (i - q0)) * Tn;
+    for (int j = threadIdx.x; j < Tn; j += blockDim.x) {
+        const T* krow = qkv + ((int64_t)b * Tn + j) * rs + E + hd * D;
+        float sdot = 0.f;
+        for (int d = 0; d < D; d++) sdot = fmaf(to_f32<T>(qrow[d]), to_f32<T>(krow[d]), sdot);
+        float v = sdot * scale;
+        if (j > i) v = -1e4f;                                          // :351-354
+        if (amask) v += amask[(int64_t)b * Tn + j];                    // :356-358
+        float pr = expf(v - l);                                        // :360
+        if (drop.thr) pr = attn_elem_hash(rowh, (uint32_t)j) >= drop.thr ? pr * drop.scale : 0.f;     // :361
+        orow[j] = pr;
+    }
+}
+
+int attn_probs_run(void* stream, const void* qkv, const float* lse, const float* amask, float* out, int B, int q0, int T, int H, int D,
+                   float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream) {
+    if (B * (T - q0) <= 0) return CMP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const DropCfg d = make_drop(p_drop, seed, rng_stream);
+    const dim3 grid(T - q0, B * H);
+    if (dtype == CMP_BF16) attn_probs_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)qkv, lse, amask, out, q0, T, H, D, sc, d);
+    else attn_probs_kernel<float><<<grid, 256, 0, s>>>((const float*)qkv, lse, amask, out, q0, T, H, D, sc, d);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
 // One-shot for the kernel-level tests that call cmp_k_attn_bwd directly (per calling thread): the next cmp_k_attn_bwd also
 // adds the column sums of [dQ | dK | dV] to out[0..3E) (the c_attn bias gradient).  The model driver passes the pointer to
 // attn_bwd_run itself.

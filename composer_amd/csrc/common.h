@@ -95,6 +95,8 @@ int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, 
                  float* bias_grad);
 int attn_fwd_run(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, float sc, int dtype, float p_drop,
                  uint64_t seed, uint32_t rng_stream, const float* amask = nullptr);
+int attn_probs_run(void* stream, const void* qkv, const float* lse, const float* amask, float* out, int B, int q0, int T, int H, int D,
+                   float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream);
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

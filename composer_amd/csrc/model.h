@@ -106,6 +106,8 @@ struct cmp_model {
     const int32_t* fwd_pos_ids = nullptr;      // cmp_forward_ex only: per-token position / token-type ids of the pass being run
     const int32_t* fwd_type_ids = nullptr;
     const float* fwd_amask = nullptr;          // ... and its additive attention mask term, float [B, past + T]
+    float* const* fwd_probs_out = nullptr;     // ... and, when asked for, L host tensors [B, H, T, past + T] for the attention weights
+    float* fwd_probs_dev = nullptr;            //     (one layer's worth of device staging)
     std::vector<LayerAct> act;
     void *hf = nullptr, *dlogits = nullptr;
     float* logits_pack = nullptr;      // [tokens, V] contiguous copy of the logits for cmp_forward's host transfer (allocated on first use)

@@ -706,6 +706,12 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         if (Tp) CHECK_RC(rows_copy(m, m->dqkv, a.qkv, B, T, 3 * Ea, T, 0, 3 * Ea, Tt, Tp, 3 * Ea));  // concat([past, new]) :423-426
         CHECK_RC(attn_fwd_run(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, attn_scale(m), dt, pa, m->drop_seed(),
                               drop_stream(step, i, 1), m->fwd_amask));
+        if (m->fwd_probs_out) {      // output_attention_weights: this layer's [B, H, T, Tt] probabilities, copied out before the next layer
+            CHECK_RC(attn_probs_run(s, a.qkv, a.lse, m->fwd_amask, m->fwd_probs_dev, B, Tp, Tt, m->H, m->D, attn_scale(m), dt, pa,
+                                    m->drop_seed(), drop_stream(step, i, 1)));
+            HIP_CHECK(hipMemcpyAsync(m->fwd_probs_out[i], m->fwd_probs_dev, (size_t)B * m->H * T * Tt * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
         const void* att = a.att;
         if (Tp) { CHECK_RC(rows_copy(m, a.att, m->tmpE, B, T, Ea, Tt, Tp, Ea, T, 0, Ea)); att = m->tmpE; }
         CHECK_RC(gemm(m, 0, wt, M, E, Ea, att, Ea, W(o.proj_w), wt ? Ea : E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, a.u, E, 0, 1, pr,
@@ -1261,7 +1267,7 @@ __global__ void logits_pack_kernel(const float* __restrict__ z, float* __restric
 
 extern "C" int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                            float* logits_out) {
-    return cmp_forward_ex(m, x, B, T, past_len, past, training, nullptr, nullptr, nullptr, logits_out);
+    return cmp_forward_ex(m, x, B, T, past_len, past, training, nullptr, nullptr, nullptr, nullptr, logits_out);
 }
 
 // (1 - mask) * -10000 (transformer.py:774-779)
@@ -1274,7 +1280,7 @@ __global__ void attention_mask_term_kernel(const int32_t* __restrict__ mask, flo
 // [B*(past_len+T)] or null (:774-779)
 extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                               const int32_t* position_ids, const int32_t* token_type_ids, const int32_t* attention_mask,
-                              float* logits_out) {
+                              float* const* attention_weights_out, float* logits_out) {
     CMP_REQUIRE(m && x && logits_out, "forward: null argument");
     CMP_REQUIRE(past_len >= 0 && (past_len == 0 || past != nullptr), "forward: past_len %d without past tensors", past_len);
     CMP_REQUIRE(T > 0 && T + past_len <= m->W, "forward: positions %d..%d exceed window_size %d (wpe rows, transformer.py:675-679,786)",
@@ -1286,8 +1292,20 @@ extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int 
     struct IdBuf {
         cmp_model* m;
         int32_t* dev = nullptr;
-        ~IdBuf() { m->fwd_pos_ids = m->fwd_type_ids = nullptr; m->fwd_amask = nullptr; if (dev) (void)hipFree(dev); }
+        ~IdBuf() {
+            m->fwd_pos_ids = m->fwd_type_ids = nullptr;
+            m->fwd_amask = nullptr;
+            m->fwd_probs_out = nullptr;
+            if (m->fwd_probs_dev) (void)hipFree(m->fwd_probs_dev);
+            m->fwd_probs_dev = nullptr;
+            if (dev) (void)hipFree(dev);
+        }
     } idbuf{m};
+    if (attention_weights_out) {
+        for (int i = 0; i < m->L; i++) CMP_REQUIRE(attention_weights_out[i], "forward: attention_weights_out[%d] is null", i);
+        HIP_CHECK(hipMalloc((void**)&m->fwd_probs_dev, (size_t)B * m->H * T * (past_len + T) * 4));
+        m->fwd_probs_out = attention_weights_out;
+    }
     if (position_ids || token_type_ids || attention_mask) {
         const int64_t n = (int64_t)B * T, nk = (int64_t)B * (past_len + T);
         if (position_ids)

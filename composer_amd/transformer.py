@@ -66,10 +66,8 @@ class Transformer:
         if use_relative_attention:
             # the reference path is broken (Attention.build reads an undefined self.depth, transformer.py:285)
             raise NotImplementedError('use_relative_attention is not supported (broken in the reference too)')
-        if output_attention_weights:
-            raise NotImplementedError('output_attention_weights is never used by the CLI path (the [B,H,T,T] probabilities are '
-                                      'never materialised here)')
         self.output_hidden_states = bool(output_hidden_states)
+        self.output_attention_weights = bool(output_attention_weights)
         self.vocab_size = vocab_size
         self.embedding_size = embedding_size
         self.window_size = window_size
@@ -255,7 +253,7 @@ class Transformer:
 
     def __call__(self, inputs, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
                  input_embeddings=None, use_cache=True, training=False):
-        """Transformer.call (transformer.py:696-833) -> (logits [B,T,V] float32, presents[, all_hidden_states]).
+        """Transformer.call (transformer.py:696-833) -> (logits [B,T,V] float32, presents[, all_hidden_states][, all_attentions]).
 
         `past` = an earlier call's presents (L tensors [2,B,H,Tp,D], or the lazy Presents object): only the last input
         token is used (:735-737), it sits at position Tp (:760-770), its keys/values are appended to `past` (:423-426)
@@ -302,9 +300,15 @@ class Transformer:
             amask = np.ascontiguousarray(np.asarray(attention_mask).astype(np.int32))
             if amask.shape != (B, past_len + T):
                 raise ValueError('attention_mask must be [batch, past_len + sequence] = %s; got %s' % ((B, past_len + T), amask.shape))
+        attentions, att_ptrs = None, None
+        if self.output_attention_weights:                                        # :360-369, 808-809: [B, H, new queries, all keys] per block
+            H = self.attention_head_count
+            attentions = [np.empty((B, H, T, past_len + T), np.float32) for _ in range(self.decoder_layers_count)]
+            att_ptrs = (C.c_void_p * len(attentions))(*[a.ctypes.data for a in attentions])
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         _lib.check(self._lib.cmp_forward_ex(self._h, x.ctypes.data_as(C.c_void_p), B, T, past_len, past_ptrs, int(bool(training)),
-                                            ptr(pos), ptr(typ), ptr(amask), logits.ctypes.data_as(C.c_void_p)), 'cmp_forward_ex')
+                                            ptr(pos), ptr(typ), ptr(amask), att_ptrs, logits.ctypes.data_as(C.c_void_p)),
+                   'cmp_forward_ex')
         gen = C.c_int64()
         _lib.check(self._lib.cmp_forward_generation(self._h, C.byref(gen)), 'cmp_forward_generation')
         outputs = (logits,)
@@ -319,6 +323,8 @@ class Transformer:
                            'cmp_hidden_get_at')
                 hidden.append(h)
             outputs += (tuple(hidden),)
+        if attentions is not None:
+            outputs += (tuple(attentions),)                                      # :827-831
         return outputs
 
     def _fetch_present(self, layer, B, T, generation):

@@ -159,10 +159,12 @@ int cmp_forward(cmp_model* m, const int32_t* x, int B, int T, int past_len, cons
  * attention_mask (:774-779, 356-358: host int32 [B*(past_len+T)], 1 = attend, 0 = masked; or null).
  *   position_ids: the wpe row of every token (default past_len + t); token_type_ids: a second wte row added to every token's
  *   embedding; attention_mask: (1 - mask) * -1e4 is added to the scaled, causally masked scores of every query of the batch
- *   row, in every layer and head.  Forward passes only (the reference's train loop passes none of them, :916-917). */
+ *   row, in every layer and head.  Forward passes only (the reference's train loop passes none of them, :916-917).
+ *   attention_weights_out (Transformer(..., output_attention_weights=True), :360-369, 808-809, 827-831): null, or L host
+ *   tensors fp32 [B, H, T, past_len + T] that receive every layer's attention probabilities after their dropout. */
 int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int past_len, const float* const* past, int training,
                    const int32_t* position_ids, const int32_t* token_type_ids, const int32_t* attention_mask,
-                   float* logits_out);
+                   float* const* attention_weights_out, float* logits_out);
 /* presents[layer] of the LAST forward pass (Transformer.call's second result, transformer.py:797-806, 820-821):
  * host fp32 [2, B, H, T, D] = stack([key, value]) after split_heads.  B, T must be that pass's shape (T = past + new). */
 int cmp_present_get(cmp_model* m, int layer, int B, int T, float* host_out);

@@ -279,6 +279,7 @@ class OracleTransformer:
             lsum = pun.sum(-1, keepdims=True)
             pr = pun / lsum                                           # :360
             prd, m_att = self._dropout(pr, c.p_attn, step, i, 1, training)   # :361
+            cache.setdefault("attentions", []).append(prd)            # all_attentions :808-809
             if self.emulate_bf16:
                 # the kernel feeds the UNNORMALISED (masked) probabilities to the matrix cores in bf16 and applies
                 # keep-scale / row sum to the fp32 output

@@ -329,8 +329,43 @@ def test_output_hidden_states_match_the_oracle(dtype, tol):
     out = m(x, use_cache=False)
     assert len(out) == 2 and len(out[1]) == L + 1 and out[1][0].shape == (B, T, E)
     m.close()
-    with pytest.raises(NotImplementedError):
-        Transformer(V, E, W, L, H, output_attention_weights=True, dtype=dtype, max_batch=B, max_seq=W)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+def test_output_attention_weights_match_the_oracle(dtype, tol):
+    """Transformer(..., output_attention_weights=True) (transformer.py:360-369, 808-809, 827-831): the call's last element holds, per
+    decoder block, the attention probabilities [B, H, queries, keys] after their dropout -- rows sum to 1 without dropout, are
+    exactly zero above the diagonal, follow an attention_mask, and cover the one new query against all keys with `past`."""
+    from composer_amd.transformer import Transformer
+    V, E, H, L, W, T, B = 390, 64, 4, 2, 48, 40, 2
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, W, L, seed=9, stddev=0.1).items()}
+    rng = np.random.default_rng(6)
+    x, _ = O.synthetic_batch(rng, V, B, T)
+    ocfg = O.Config(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1)
+    orc = O.OracleTransformer(ocfg, {k: v.astype(np.float64) for k, v in params.items()}, seed=17, emulate_bf16=(dtype == "bf16"))
+    m = Transformer(V, E, W, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, output_hidden_states=True,
+                    output_attention_weights=True, dtype=dtype, seed=17, max_batch=B, max_seq=W)
+    m.set_weights(params)
+    mask = (rng.random((B, T)) > 0.25).astype(np.int32)
+    mask[:, 0] = 1
+    for kw in (dict(), dict(training=True), dict(attention_mask=mask)):
+        logits, pres, hidden, att = m(x, **kw)
+        _, opast, cache = orc.forward(x, step=0, **kw)
+        assert len(att) == L and len(hidden) == L + 1
+        for i in range(L):
+            assert att[i].shape == (B, H, T, T) and att[i].dtype == np.float32
+            assert np.abs(att[i] - cache["attentions"][i]).max() <= tol, (i, sorted(kw))
+            assert not np.triu(att[i], 1).any()
+        if not kw.get("training"):
+            assert np.abs(att[0].sum(-1) - 1.0).max() <= (1e-5 if dtype == "fp32" else 2e-2)
+    logits, pres, hidden, att = m(np.concatenate([x, x[:, :1]], 1), past=pres,
+                                  attention_mask=np.concatenate([mask, np.ones((B, 1), np.int32)], 1))
+    _, _, cache = orc.forward(x[:, :1], past=opast, attention_mask=np.concatenate([mask, np.ones((B, 1), np.int32)], 1))
+    assert att[L - 1].shape == (B, H, 1, T + 1)
+    assert np.abs(att[L - 1] - cache["attentions"][L - 1]).max() <= tol
+    out = m(x, use_cache=False)
+    assert len(out) == 3 and len(out[2]) == L
+    m.close()
 
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
