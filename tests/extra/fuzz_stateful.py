@@ -54,7 +54,7 @@ def run_model(rng, nops, log):
     lr = 1e-3
     try:
         for _ in range(nops):
-            op = str(rng.choice(["train", "train", "async", "grads", "eval", "fwd", "past", "fwd_train", "gen_kv", "gen_lit", "reload", "setw", "bad"]))
+            op = str(rng.choice(["train", "train", "async", "grads", "eval", "fwd", "fwd_kw", "past", "fwd_train", "gen_kv", "gen_lit", "reload", "setw", "bad"]))
             B = int(rng.integers(1, maxB + 1)); T = int(rng.integers(1, W + 1))
             x, y = O.synthetic_batch(rng, V, B, T)
             log.append((op, B, T))
@@ -91,6 +91,22 @@ def run_model(rng, nops, log):
                 lg, pres = m(x)
                 want, opast, _ = orc.forward(x)
                 close(lg, want, 2e-4 * k / 4, "logits")
+                close(np.array(pres[L - 1]), opast[L - 1], 3e-5 * k, "presents")
+            elif op == "fwd_kw":
+                # the rest of Transformer.call's signature: position / token-type ids, attention mask (key 0 always kept: a fully
+                # masked row is held to a looser bound in tests/test_gpu_model.py), with and without the train-step dropout
+                kw = {}
+                if rng.random() < 0.6:
+                    kw["position_ids"] = rng.integers(0, W, size=(B if rng.random() < 0.5 else 1, T)).astype(np.int32)
+                if rng.random() < 0.5:
+                    kw["token_type_ids"] = rng.integers(0, min(V, 2), size=(B, T)).astype(np.int32)
+                if rng.random() < 0.6:
+                    am = (rng.random((B, T)) > 0.3).astype(np.int32); am[:, 0] = 1
+                    kw["attention_mask"] = am
+                tr = bool(rng.random() < 0.4)
+                lg, pres = m(x, training=tr, **kw)
+                want, opast, _ = orc.forward(x, training=tr and p > 0, step=orc.iterations, **kw)
+                close(lg, want, 2e-4 * k / 4, "logits with " + ",".join(sorted(kw)))
                 close(np.array(pres[L - 1]), opast[L - 1], 3e-5 * k, "presents")
             elif op == "past":
                 if T == W:

@@ -392,12 +392,13 @@ def test_attention_fwd_bwd(lib, dtype, B, T, H, D, p):
     ref = x.grad.reshape(B * T, 3 * E)
     assert rel_err(bias_grad, ref.sum(0) + 2.0) < tol
     assert rel_err(delta, (do.double() * o.double()).reshape(B, T, H, D).sum(-1).permute(0, 2, 1).reshape(-1)) < tol
-    # per slice, relative to that slice's largest reference value -- but not to less than 1 % of the whole gradient's: at T = 1
-    # dq is exactly zero in exact arithmetic (p = 1, dp = delta) and the kernel's dp - delta is a rounding residue of o
+    # per slice, relative to that slice's largest reference value -- but not to less than 10 % of the whole gradient's: at T = 1
+    # dq is exactly zero in exact arithmetic (p = 1, dp = delta) and the kernel's dp - delta is the rounding residue of the
+    # stored o (bf16 with dropout: ~2^-9 of |dO.v|, i.e. ~1e-3 of the gradient's scale)
     whole = ref.abs().max().item()
     for name, sl in (("dq", slice(0, E)), ("dk", slice(E, 2 * E)), ("dv", slice(2 * E, 3 * E))):
         err = (dqkv[:, sl].double().cpu() - ref[:, sl]).abs().max().item()
-        assert err / max(ref[:, sl].abs().max().item(), 1e-2 * whole, 1e-30) < tol * 2, name
+        assert err / max(ref[:, sl].abs().max().item(), 0.1 * whole, 1e-30) < tol * 2, name
 
 
 def check_attention_groups(lib, B, H, D, T, dtype, p, groups):
