@@ -483,6 +483,15 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     const T* vg = qg + 2 * E;
     T* og = o + (int64_t)b * Tn * E + hd * D;
     const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    // Deferred rescale (throughput mode): the running maximum m is only raised -- and O, l rescaled -- when some row's new maximum
+    // exceeds it by more than 2^RESCALE_LOG2 in the probability domain; until then the probabilities are taken against the stale
+    // maximum (at most 2^RESCALE_LOG2, exact in fp32 sums and as bf16 operands) and O / l stays the same quotient.  With random
+    // scores some row of a wave sets a new maximum in nearly every tile, so the exact vote rescaled (34 multiplies and an
+    // exponential per lane) almost always; the deferred one does so on the first tile of a row and rarely after.
+#ifndef ATTN_RESCALE_LOG2
+#define ATTN_RESCALE_LOG2 8.0f
+#endif
+    const float rescale_raw = ATTN_RESCALE_LOG2 / c2;
     const float* am = AMASK ? amask + (int64_t)b * Tn : nullptr;
     const float inv_scale = 1.0f / scale;           // throughput mode works on raw scores: the mask term goes in divided by the scale
 
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
                 const float mloc = half_max(fmaxf(max16(s0), max16(s1)));
 #endif
                 const float mnew = fmaxf(m, mloc);
-                if (!__all(mnew == m)) {
+                if (!__all(mnew <= m + rescale_raw)) {
                     const float alpha = fast_exp2((m - mnew) * c2);
                     lsum *= alpha;
 #pragma unroll
@@ -653,7 +662,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
                     float mloc = max16(s);
                     mloc = half_max(mloc);
                     const float mnew = fmaxf(m, mloc);
-                    if (!__all(mnew == m)) {
+                    if (!__all(mnew <= m + rescale_raw)) {
                         const float alpha = fast_exp2((m - mnew) * c2);
                         lsum *= alpha;
 #pragma unroll
