@@ -10,6 +10,7 @@ FUZZ_DP=1 f timeout 600 python tests/extra/fuzz_stateful.py 20 40 $((s+3))
 FUZZ_DTYPE=bf16 f timeout 600 python tests/extra/fuzz_stateful.py 20 40 $((s+4))
 f timeout 600 python tests/extra/fuzz_gemm.py 200 $((s+5))
 f timeout 600 python tests/extra/fuzz_attention.py 100 $((s+6))
+f timeout 900 python tests/extra/fuzz_attention_plans.py 40 $((s+7))
 f timeout 300 python tools/leak_probe.py 40
 f timeout 300 python tools/soak_probe.py 2000
 COMPOSER_DETERMINISTIC=1 THREAD_MODELS=3 f timeout 300 python tools/thread_probe.py 60
