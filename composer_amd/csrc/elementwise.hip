@@ -577,6 +577,85 @@ __global__ void softmax_xent_kernel(const float* __restrict__ z, int ldz, const 
     }
 }
 
+// The same for rows of at most 512 columns whose stride is a multiple of 8: a lane owns EIGHT CONSECUTIVE columns -- two 16-byte
+// loads and one 16-byte (bf16) gradient store per row and lane where the kernel above issues seven 4-byte loads and seven
+// 2-byte stores; one exponential per element (the gradient is e * (1 / sum)); the next row is requested before the current one
+// is reduced.  Ties: the lowest column wins (ascending inside a lane, lower lane = lower columns).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_xent8_kernel(const float* __restrict__ z, int ldz, const int32_t* __restrict__ y,
+                                                            T* __restrict__ dz, float* __restrict__ row_loss,
+                                                            int32_t* __restrict__ row_correct, int rows, int V, float inv_n) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int c0 = 8 * lane;
+    const bool active = c0 < ldz;
+    const int stride = gridDim.x * wpb;
+    int row = blockIdx.x * wpb + (threadIdx.x >> 6);
+    f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
+    int ny = 0;
+    auto fetch = [&](int r) {
+        if (active) {
+            n0 = *reinterpret_cast<const f32x4*>(z + (int64_t)r * ldz + c0);
+            n1 = *reinterpret_cast<const f32x4*>(z + (int64_t)r * ldz + c0 + 4);
+        }
+        ny = y[r];
+    };
+    if (row < rows) fetch(row);
+    for (; row < rows; row += stride) {
+        float v[8] = {n0[0], n0[1], n0[2], n0[3], n1[0], n1[1], n1[2], n1[3]};
+        const int yy = ny;
+        if (row + stride < rows) fetch(row + stride);
+        float mx = -INFINITY;
+        int arg = 0x7fffff;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (!active || c0 + j >= V) v[j] = -INFINITY;
+            if (v[j] > mx) {       // strict >: the lowest column of the lane
+                mx = v[j];
+                arg = c0 + j;
+            }
+        }
+        const float gmx = wave_max(mx);
+        // lowest column among the lanes that hold the maximum (column numbers are exact in fp32)
+        const int garg = (int)(-wave_max(mx == gmx ? -(float)arg : -8388607.0f));
+        float e[8], ssum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            e[j] = expf(v[j] - gmx);                 // exp(-inf) = 0 for the padding columns
+            ssum += e[j];
+        }
+        ssum = wave_sum(ssum);
+        const float lse = gmx + logf(ssum);
+        if (dz && active) {
+            const float inv = 1.0f / ssum;
+            Vec16<T> o0, o1;                          // fp32: two 16-byte stores; bf16: one
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) g[j] = (c0 + j < V) ? (e[j] * inv - (c0 + j == yy ? 1.0f : 0.0f)) * inv_n : 0.f;
+            T* dr = dz + (int64_t)row * ldz + c0;
+            if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { o0.set(j, g[j]); o1.set(j, g[4 + j]); }
+                st16(dr, o0);
+                st16(dr + 4, o1);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) o0.set(j, g[j]);
+                st16(dr, o0);
+            }
+        }
+        float zy = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j == (yy & 7)) zy = v[j];
+        zy = __shfl(zy, yy >> 3);
+        if (lane == 0) {
+            row_loss[row] = lse - zy;
+            row_correct[row] = (garg == yy) ? 1 : 0;
+        }
+    }
+}
+
 // the same for any vocabulary size (ldz > 64 * XENT_MAXI): three passes over the row, which stays in L1/L2 between them
 template <typename T>
 __global__ void softmax_xent_wide_kernel(const float* __restrict__ z, int ldz, const int32_t* __restrict__ y,
@@ -978,6 +1057,11 @@ extern "C" int cmp_k_softmax_xent(void* stream, const float* logits, int ldz, co
             softmax_xent_wide_kernel<bf16_t><<<grid, 256, 0, s>>>(logits, ldz, y, (bf16_t*)dlogits, row_loss, row_correct, rows, V, inv_n);
         else
             softmax_xent_wide_kernel<float><<<grid, 256, 0, s>>>(logits, ldz, y, (float*)dlogits, row_loss, row_correct, rows, V, inv_n);
+    } else if (ldz % 8 == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0) {
+        if (dtype == CMP_BF16)
+            softmax_xent8_kernel<bf16_t><<<grid, 256, 0, s>>>(logits, ldz, y, (bf16_t*)dlogits, row_loss, row_correct, rows, V, inv_n);
+        else
+            softmax_xent8_kernel<float><<<grid, 256, 0, s>>>(logits, ldz, y, (float*)dlogits, row_loss, row_correct, rows, V, inv_n);
     } else if (dtype == CMP_BF16)
         softmax_xent_kernel<bf16_t><<<grid, 256, 0, s>>>(logits, ldz, y, (bf16_t*)dlogits, row_loss, row_correct, rows, V, inv_n);
     else
