@@ -88,6 +88,11 @@ SIGNATURES = {
     "cmp_k_layernorm_bwd_ws": (_i64, [_i, _i]),
     "cmp_k_layernorm_bwd_fused": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _P, _f, _u64, _u32]),
     "cmp_k_gemm": (_i, [_P, _i, _i, _i, _i, _i, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _P, _i, _i, _i, _f, _u64, _u32, _i]),
+    "cmp_k_embed_fwd_stats": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _f, _u64, _u32]),
+    "cmp_k_ln_fold_prep": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i]),
+    "cmp_gemm_ln_next": (_i, [_P, _i, _f, _P, _P, _P, _P]),
+    "cmp_k_layernorm_bwd_parts": (_i, [_P, _P, _P, _P, _P, _P, _f, _P, _P, _P, _P, _P, _P, _i, _i, _P, _P, _f, _u64, _u32]),
+    "cmp_model_path_info": (_i, [_P, C.POINTER(_i), C.POINTER(_i64)]),
     "cmp_k_wgrad_group": (_i, [_P, _i, _P, _P, _P, _P, _P, _P, _P, _P, _i]),
     "cmp_gemm_set_workspace": (_i, [_P, _i64]),
     "cmp_gemm_colsum_next": (_i, [_P]),
@@ -102,7 +107,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
+_ADDED_LATER = {"cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
 
 _lib = None
 

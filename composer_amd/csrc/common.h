@@ -63,13 +63,48 @@ struct SchedWs {
     int parity = 0;
     bool dirty = false;          // a launch that used the counters failed: both sets are re-zeroed before the next use
 };
+// LayerNorm folded into the epilogues of the forward GEMMs (gemm.hip: epi_tile<.., LNM, NP>; full 256x256 tiles, bf16).  The
+// statistics of a row travel as PARTIALS: (mean, M2 = sum of squared deviations from that mean) of every 256-column segment of
+// the row, written by the epilogue of the GEMM (or the embedding kernel) that produced the row and merged by whoever consumes
+// it (Chan's parallel update -- never a sum of squares).
+//   consumer, fold (c_attn / c_fc: transformer.py:583-584,591 followed by Conv1D :205-209):
+//       LN(x).W + b = rstd * (x.(gamma o W)) - rstd*mean * colsum(gamma o W) + (beta.W + b)
+//     the GEMM runs on the RAW rows x and the gamma-scaled weight shadow; `cs` = colsum of that shadow, bias = beta.W + b.
+//   consumer, residual (attention c_proj, :587 r = LN1(x) + dropout(proj)): the residual operand is rebuilt from the raw
+//     row, its statistics and gamma / beta.
+//   producer (both c_proj): the epilogue owns a 256-column tile of every output row and emits that segment's partial.
+struct LnEpi {
+    const float* in_part = nullptr;   // [rows][np][2] partial statistics of the LayerNorm input's rows (null: no LayerNorm on the way in)
+    int np = 0;                       // segments per row = E / 256
+    float eps = 0.f;
+    const float* cs = nullptr;        // fold: [N] column sums of the gamma-scaled bf16 weight
+    const float* gamma = nullptr;     // residual rebuild: [N] gamma, beta of the LayerNorm whose output is the residual operand
+    const float* beta = nullptr;
+    float* out_part = nullptr;        // [rows][N / 256][2] partial statistics of the OUTPUT rows (null: not wanted)
+};
+// (mean, rstd) of a row from its np partials of 256 columns each
+__device__ __forceinline__ void ln_merge_parts(const float* __restrict__ p, int np, float eps, float& mean, float& rstd) {
+    float mu = 0.f;
+    for (int s = 0; s < np; s++) mu += p[2 * s];
+    mu /= (float)np;
+    float m2 = 0.f;
+    for (int s = 0; s < np; s++) {
+        const float d = p[2 * s] - mu;
+        m2 += p[2 * s + 1] + 256.0f * d * d;
+    }
+    mean = mu;
+    rstd = __builtin_amdgcn_rsqf(m2 / (256.0f * (float)np) + eps);
+}
+
 struct GemmExtra {
+    LnEpi ln;                    // LayerNorm fused into this launch's epilogue (forward GEMMs of the fused block path, model.hip)
     float* colsum = nullptr;     // also add the column sums of the output to colsum[0..N) (the bias gradient that goes with an
                                  // input-gradient GEMM); fused into the epilogue where possible, else a colsum pass after it
     float* slab_ws = nullptr;    // split-K: per-split fp32 partial tiles + fixed-order reduce instead of float atomics
     size_t slab_bytes = 0;
     int role = -1;               // cmp_prof_* timing class: 0 forward, 1 dgrad, 2 wgrad, -1 = by operand layout
     int max_wgs = 0;             // cap on the persistent kernels' grid (CUs left to a concurrent RCCL kernel); 0 = all 256
+    bool rev = false;            // persistent 256x256 kernel: walk every XCD group's run of tiles from its end (gemm.hip: item_coords)
     bool dp = false;             // the launch belongs to a data-parallel job: persistent kernels hand their items out dynamically
     SchedWs* sched = nullptr;    // the calling context's item-counter workspace (a cmp_ctx is single-threaded by contract: no lock)
 };
@@ -83,6 +118,7 @@ struct WgradGroup {              // owned by the caller, one per call site whose
     std::string host;            // the bytes uploaded (kept until the next rebuild: the upload is stream-ordered)
     int nitems = 0, grid = 0;    // nitems == 0 with a key: the cost model chose one launch per problem for these shapes
     bool force = false;          // use the grouped launch even where the cost model prefers separate launches (kernel-level tests)
+    int64_t rebuilds = 0;        // item tables built so far (a steady train loop builds each block's once: cmp_wgrad_group_rebuilds)
 };
 // returns CMP_OK with *handled = false when the shapes do not fit the grouped kernel (the caller then runs the problems one by one)
 int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int nprob, int K, const GemmExtra& ex, bool* handled);

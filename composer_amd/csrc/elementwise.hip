@@ -45,6 +45,59 @@ __global__ void embed_fwd_kernel(const int32_t* __restrict__ ids, const float* _
     }
 }
 
+// The same sum, one wave per token row, for the LayerNorm-fused block path (model.hip: model_forward): besides the row it
+// leaves the row's partial statistics -- (mean, M2) of every 256-column segment of the STORED bf16 values -- for the c_attn
+// epilogue of block 0, which applies ln_1 itself (common.h: LnEpi).  A lane owns the 16-byte chunks lane + 64 i; 32 chunks
+// make a segment, so a segment is one half of the wave at one i.
+template <int MAXI>
+__global__ __launch_bounds__(256) void embed_fwd_stats_kernel(const int32_t* __restrict__ ids, const float* __restrict__ wte,
+                                                               const float* __restrict__ wpe, bf16_t* __restrict__ out,
+                                                               float* __restrict__ part, int ntok, int T_, int E, int pos0, DropCfg drop) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int chunks = E >> 3, np = E >> 8;
+    for (int tok = blockIdx.x * wpb + (threadIdx.x >> 6); tok < ntok; tok += gridDim.x * wpb) {
+        const int id = ids[tok], t = tok % T_;
+        const uint32_t rowh = drop_row_hash(drop, (uint32_t)tok);
+#pragma unroll
+        for (int i = 0; i < MAXI; i++) {
+            const int c = lane + 64 * i;
+            const bool live = c < chunks;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) f[j] = 0.f;
+            if (live) {
+                const float* a = wte + (int64_t)id * E + c * 8;
+                const float* p = wpe + (int64_t)(pos0 + t) * E + c * 8;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(p), p1 = *reinterpret_cast<const f32x4*>(p + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float v = j < 4 ? a0[j] + p0[j] : a1[j - 4] + p1[j - 4];
+                    if (drop.thr) v = apply_drop_rc(drop, rowh, (uint32_t)(c * 8 + j), v);
+                    o[j] = (bf16_t)v;
+                    f[j] = (float)o[j];
+                }
+                *reinterpret_cast<bf16x8*>(out + (int64_t)tok * E + c * 8) = o;
+            }
+            // the segment's mean, then its squared deviations (two passes over registers), each summed over the half-wave
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) sm += f[j];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            const float mu = sm * (1.0f / 256.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float d = f[j] - mu; q = fmaf(d, d, q); }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const int seg = c >> 5;
+            if (live && (lane & 31) == 0) *reinterpret_cast<f32x2*>(part + ((int64_t)tok * np + seg) * 2) = (f32x2){mu, q};
+        }
+    }
+}
+
 // dwte[x[b,t],:] += dh[b,t,:] (f32 atomics, 256 contiguous bytes per wave-instruction);
 // dwpe[pos0+t,:] += sum_b dh[b,t,:].   One thread per (t, e); loops over b.
 template <typename T>
@@ -356,13 +409,17 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
 
 // dx = resid + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;  partial dgamma/dbeta per workgroup
 // into ws[wg][2][E]; ln_param_reduce_kernel folds them into dgamma/dbeta.
-template <typename T, int MAXI>
+// FUSED (the LayerNorm-fused block path, bf16): the forward pass never ran this LayerNorm as a kernel -- its statistics arrive as
+// the partials the producing GEMM epilogue left (`part`, np segments of 256 columns, merged here), and its OUTPUT, which only
+// the weight-gradient GEMM of the consuming Conv1D needs, is written here (`yout` = xhat * gamma + beta) beside dx.
+template <typename T, int MAXI, bool FUSED = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const T* __restrict__ resid,
                                      T* __restrict__ dx, float* __restrict__ ws, int rows, int E,
                                      T* __restrict__ dmask, int want_colsum, DropCfg drop,
-                                     float* __restrict__ direct_g, float* __restrict__ direct_b, float* __restrict__ direct_cs) {
+                                     float* __restrict__ direct_g, float* __restrict__ direct_b, float* __restrict__ direct_cs,
+                                     LnBwdFused fz = LnBwdFused()) {
     // optional fused consumer prologue: the output dx is the gradient of a residual branch's dropout output
     // (x + dropout(proj(..))): dmask = dx * mask/(1-p) feeds that projection's wgrad/dgrad and its column sums are the
     // projection's bias gradient (third partial, ws[wg][2] -> cs)
@@ -371,7 +428,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     const int chunks = E / VN;
-    float dg[MAXI][VN], db[MAXI][VN], gm[MAXI][VN], cs[MAXI][VN];
+    float dg[MAXI][VN], db[MAXI][VN], gm[MAXI][VN], cs[MAXI][VN], be[FUSED ? MAXI : 1][VN];
 #pragma unroll
     for (int i = 0; i < MAXI; i++) {
         int c = lane + 64 * i;
@@ -381,8 +438,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             db[i][j] = 0.f;
             cs[i][j] = 0.f;
             gm[i][j] = (c < chunks) ? gamma[c * VN + j] : 0.f;
+            if (FUSED) be[i][j] = (c < chunks) ? fz.beta[c * VN + j] : 0.f;
         }
     }
+    constexpr int NPMAX = 2 * MAXI;             // segments of 256 columns in a row of at most 64 * MAXI chunks of 8
     // Software pipeline over the rows of this wave: the three input rows (dy, x, residual) and the statistics of the NEXT
     // row are requested before the current row is reduced and written, so ~6 KiB per wave (~96 KiB per CU at 4 waves
     // per SIMD) stay in flight.  (Before: dy/x, two wave reductions, THEN the residual row -- two exposed HBM latencies
@@ -390,10 +449,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     struct RowIn {
         Vec16<T> dy[MAXI], x[MAXI], r[MAXI];
         float mu, rs;
+        f32x2 pt[FUSED ? NPMAX : 1];           // the row's partial statistics, merged when the row is reduced
     };
     auto fetch = [&](int row, RowIn& in) {
-        in.mu = mean[row];
-        in.rs = rstd[row];
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int sg = 0; sg < NPMAX; sg++)
+                in.pt[sg] = sg < fz.np ? *reinterpret_cast<const f32x2*>(fz.part + ((int64_t)row * fz.np + sg) * 2) : (f32x2){0.f, 0.f};
+        } else {
+            in.mu = mean[row];
+            in.rs = rstd[row];
+        }
 #pragma unroll
         for (int i = 0; i < MAXI; i++) {
             const int c = lane + 64 * i;
@@ -411,7 +477,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (; row < rows; row += stride) {
         const bool more = row + stride < rows;
         if (more) fetch(row + stride, nxt);
-        const float mu = cur.mu, rs = cur.rs;
+        float mu = cur.mu, rs = cur.rs;
+        if constexpr (FUSED) {
+            float a = 0.f;
+#pragma unroll
+            for (int sg = 0; sg < NPMAX; sg++) a += cur.pt[sg][0];                 // (absent segments hold zeros)
+            mu = a / (float)fz.np;
+            float m2 = 0.f;
+#pragma unroll
+            for (int sg = 0; sg < NPMAX; sg++) {
+                const float d = cur.pt[sg][0] - mu;
+                if (sg < fz.np) m2 += cur.pt[sg][1] + 256.0f * d * d;
+            }
+            rs = __builtin_amdgcn_rsqf(m2 / (256.0f * (float)fz.np) + fz.eps);
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXI; i++) {
@@ -436,7 +515,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
-                Vec16<T> o, om;
+                Vec16<T> o, om, oy;
 #pragma unroll
                 for (int j = 0; j < VN; j++) {
                     float xh = (cur.x[i].get(j) - mu) * rs;
@@ -444,7 +523,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     float v = rs * (g - s1 - xh * s2);
                     if (resid) v += cur.r[i].get(j);
                     o.set(j, v);
-                    if (want_colsum) {
+                    if (FUSED) oy.set(j, xh * gm[i][j] + be[i][j]);
+                    if (want_colsum || dmask) {
                         // the consumer sees the STORED (rounded) value
                         float vm = drop.thr ? apply_drop_rc(drop, rowh, (uint32_t)(c * VN + j), o.get(j)) : o.get(j);
                         om.set(j, vm);
@@ -453,6 +533,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 }
                 st16(dx + (int64_t)row * E + c * VN, o);
                 if (dmask) st16(dmask + (int64_t)row * E + c * VN, om);
+                if constexpr (FUSED) { if (fz.yout) st16((T*)fz.yout + (int64_t)row * E + c * VN, oy); }
             }
         }
         if (more) cur = nxt;
@@ -869,6 +950,109 @@ int embed_fwd_run(void* stream, const int32_t* ids, const float* wte, const floa
     return CMP_OK;
 }
 
+int embed_fwd_stats_run(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, float* part, int B, int T,
+                        int E, int pos0, float p_drop, uint64_t seed, uint32_t rng_stream) {
+    CMP_REQUIRE(E % 256 == 0 && E <= 2048, "embed_fwd_stats: E=%d must be a multiple of 256, at most 2048", E);
+    hipStream_t s = (hipStream_t)stream;
+    DropCfg d = make_drop(p_drop, seed, rng_stream);
+    const int ntok = B * T;
+    if (ntok == 0) return CMP_OK;
+    const int grid = std::min(cdiv(ntok, 4), 8192), maxi = cdiv(E / 8, 64);
+#define EMB_ST(MI) embed_fwd_stats_kernel<MI><<<grid, 256, 0, s>>>(ids, wte, wpe, (bf16_t*)out, part, ntok, T, E, pos0, d)
+    if (maxi == 1) EMB_ST(1); else if (maxi == 2) EMB_ST(2); else EMB_ST(4);
+#undef EMB_ST
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+extern "C" int cmp_k_embed_fwd_stats(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, float* part,
+                                     int B, int T, int E, int pos0, float p_drop, uint64_t seed, uint32_t rng_stream) {
+    return embed_fwd_stats_run(stream, ids, wte, wpe, out, part, B, T, E, pos0, p_drop, seed, rng_stream);
+}
+
+// ---- LayerNorm fold, weight side (common.h: LnEpi).  For every Conv1D that consumes a LayerNorm output (c_attn <- ln_1, c_fc <-
+// ln_2; transformer.py:583-584,591) one pass over the fp32 master weight W [rows = E][cols = N] writes
+//   WT[n][k] = bf16(gamma[k] * W[k][n])      the K-contiguous operand of the forward GEMM on the RAW rows
+//   cs[n]    = sum_k float(WT[n][k])         (of the ROUNDED values: what the matrix cores multiply by)
+//   bias'[n] = bias[n] + sum_k beta[k] * W[k][n]
+// A workgroup owns 32 columns and walks the rows in 32x32 tiles through LDS (transposed store); no atomics: reproducible.
+__global__ __launch_bounds__(256) void ln_fold_prep_kernel(const float* __restrict__ P, bf16_t* __restrict__ ST, float* __restrict__ fold,
+                                                           const FoldDesc* __restrict__ desc) {
+    __shared__ bf16_t tile[32][34];
+    __shared__ float red[2][8][33];
+    const FoldDesc d = desc[blockIdx.y];
+    const int c0 = blockIdx.x * 32;
+    if (c0 >= d.cols) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const float* __restrict__ W = P + d.w_off;
+    const float* __restrict__ g = P + d.g_off;
+    const float* __restrict__ be = P + d.be_off;
+    bf16_t* __restrict__ dst = ST + d.w_off;
+    float acs = 0.f, abb = 0.f;
+    for (int r0 = 0; r0 < d.rows; r0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = r0 + ty + 8 * j;
+            const float w = W[(int64_t)r * d.cols + c0 + tx];
+            const bf16_t ws = (bf16_t)(g[r] * w);
+            acs += (float)ws;
+            abb = fmaf(be[r], w, abb);
+            tile[ty + 8 * j][tx] = ws;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) dst[(int64_t)(c0 + ty + 8 * j) * d.rows + r0 + tx] = tile[tx][ty + 8 * j];
+        __syncthreads();
+    }
+    red[0][ty][tx] = acs;
+    red[1][ty][tx] = abb;
+    __syncthreads();
+    if (ty == 0) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a += red[0][k][tx]; b += red[1][k][tx]; }
+        fold[d.out_off + c0 + tx] = a;
+        fold[d.out_off + d.cols + c0 + tx] = P[d.b_off + c0 + tx] + b;
+    }
+}
+int ln_fold_prep_run(void* stream, const float* P, void* ST, float* fold, const void* desc_dev, int ndesc, int max_cols) {
+    if (ndesc <= 0) return CMP_OK;
+    ln_fold_prep_kernel<<<dim3(cdiv(max_cols, 32), ndesc), 256, 0, (hipStream_t)stream>>>(P, (bf16_t*)ST, fold, (const FoldDesc*)desc_dev);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+// kernel-level entry point (tests): ONE matrix, operands given separately.  W fp32 [E, N], bias [N], gamma / beta [E] ->
+// WT bf16 [N, E], cs [N], bias_out [N].  E and N multiples of 32.
+extern "C" int cmp_k_ln_fold_prep(void* stream, const float* W, const float* bias, const float* gamma, const float* beta, void* WT,
+                                  float* cs, float* bias_out, int E, int N) {
+    CMP_REQUIRE(E > 0 && N > 0 && E % 32 == 0 && N % 32 == 0, "ln_fold_prep: E=%d N=%d must be multiples of 32", E, N);
+    // one flat staging buffer laid out like the model's (P: W | bias | gamma | beta; fold: cs | bias'), copied in and out on the stream
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nW = (int64_t)E * N;
+    float* Pb = nullptr; float* fold = nullptr; FoldDesc* dd = nullptr;
+    HIP_CHECK(hipMalloc((void**)&Pb, (size_t)(nW + N + 2 * E) * 4));
+    hipError_t e = hipMalloc((void**)&fold, (size_t)2 * N * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dd, sizeof(FoldDesc));
+    FoldDesc h{0, nW, nW + N, nW + N + E, 0, E, N};
+    if (e == hipSuccess) e = hipMemcpyAsync(Pb, W, (size_t)nW * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(Pb + nW, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(Pb + nW + N, gamma, (size_t)E * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(Pb + nW + N + E, beta, (size_t)E * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dd, &h, sizeof(h), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int rc = CMP_OK;
+    if (e == hipSuccess) {
+        // (the kernel writes ST + w_off with w_off = 0: WT itself)
+        rc = ln_fold_prep_run(stream, Pb, WT, fold, dd, 1, N);
+        if (rc == CMP_OK) e = hipMemcpyAsync(cs, fold, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
+        if (rc == CMP_OK && e == hipSuccess) e = hipMemcpyAsync(bias_out, fold + N, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(Pb); (void)hipFree(fold); (void)hipFree(dd);
+    if (rc != CMP_OK) return rc;
+    HIP_CHECK(e);
+    return CMP_OK;
+}
+
 // int32 words of the sorted form's workspace for ntok tokens and V ids (0: the vocabulary does not fit the LDS histogram)
 int64_t embed_bwd_sort_ws_words(int64_t ntok, int V) {
     if (V <= 0 || V > 8192) return 0;
@@ -1004,13 +1188,26 @@ extern "C" int cmp_k_layernorm_bwd_fused(void* stream, const void* dy, const voi
                                          void* ws, int rows, int E, int dtype, void* dmask, float* colsum, float p_drop,
                                          uint64_t seed, uint32_t rng_stream) {
     return layernorm_bwd_run(stream, dy, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, ws, rows, E, dtype, dmask, colsum, p_drop,
-                             seed, rng_stream, false);
+                             seed, rng_stream, false, nullptr, false);
+}
+// The form the LayerNorm-fused block path uses (bf16, E a multiple of 256): the row statistics come as partials [rows][E/256][2]
+// (mean, M2 per 256-column segment, as the producing GEMM epilogue / embedding kernel leaves them) and the LayerNorm OUTPUT
+// yout = xhat * gamma + beta is written beside dx (null: not wanted).  dmask (null: not wanted) is written whatever p_drop is.
+extern "C" int cmp_k_layernorm_bwd_parts(void* stream, const void* dy, const void* x, const float* gamma, const float* beta,
+                                         const float* part, float eps, const void* resid, void* dx, void* yout, float* dgamma,
+                                         float* dbeta, void* ws, int rows, int E, void* dmask, float* colsum, float p_drop,
+                                         uint64_t seed, uint32_t rng_stream) {
+    LnBwdFused fz;
+    fz.part = part; fz.np = E / 256; fz.eps = eps; fz.beta = beta; fz.yout = yout;
+    return layernorm_bwd_run(stream, dy, x, gamma, nullptr, nullptr, resid, dx, dgamma, dbeta, ws, rows, E, CMP_BF16, dmask, colsum, p_drop,
+                             seed, rng_stream, false, &fz, true);
 }
 
 // deterministic: the per-workgroup partials are folded by ONE thread per column in workgroup order (no float atomics)
 int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* resid, void* dx, float* dgamma, float* dbeta, void* ws, int rows, int E, int dtype, void* dmask,
-                      float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic) {
+                      float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic, const LnBwdFused* fz,
+                      bool keep_dmask) {
     int rc = ln_check(E, dtype);
     if (rc) return rc;
     if (rows == 0) return CMP_OK;
@@ -1020,7 +1217,10 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
     const int vn = dtype == CMP_BF16 ? 8 : 4;
     const int maxi = cdiv(E / vn, 64);
     DropCfg dcfg = make_drop(p_drop, seed, rng_stream);
-    if (p_drop <= 0.f) dmask = nullptr;          // no mask: the consumer reads dx itself
+    if (fz) CMP_REQUIRE(dtype == CMP_BF16 && fz->part && fz->beta && E % 256 == 0 && fz->np == E / 256,
+                        "layernorm_bwd: the statistics-from-partials form needs bf16 rows of a multiple of 256 columns (E=%d, np=%d)", E, fz->np);
+    // no mask: the consumer reads dx itself (the fused block path keeps the copy: there dx is overwritten before the weight gradients read it)
+    if (p_drop <= 0.f && !fz && !keep_dmask) dmask = nullptr;
     PROF_START(8, s);
     const int want_cs = colsum != nullptr;
     // up to 256 workgroups (rows <= 2048) the per-workgroup partials go to the gradients by atomics from the kernel itself; beyond
@@ -1032,14 +1232,20 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
         if (smem > 65536) HIP_CHECK(hipFuncSetAttribute((const void*)layernorm_bwd_kernel<TT, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         layernorm_bwd_kernel<TT, MI><<<grid, 256, smem, s>>>((const TT*)dy, (const TT*)x, gamma, mean, rstd, (const TT*)resid, (TT*)dx, (float*)ws, rows, E, (TT*)dmask, want_cs, dcfg, dg_, dbeta, colsum); \
     } while (0)
-    if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else if (maxi <= 4) LN_BWD(bf16_t, 4); else LN_BWD(bf16_t, 8); }
+#define LN_BWDF(MI) do { \
+        if (smem > 65536) HIP_CHECK(hipFuncSetAttribute((const void*)layernorm_bwd_kernel<bf16_t, MI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        layernorm_bwd_kernel<bf16_t, MI, true><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)resid, (bf16_t*)dx, (float*)ws, rows, E, (bf16_t*)dmask, want_cs, dcfg, dg_, dbeta, colsum, *fz); \
+    } while (0)
+    if (fz) { if (maxi == 1) LN_BWDF(1); else if (maxi == 2) LN_BWDF(2); else if (maxi <= 4) LN_BWDF(4); else LN_BWDF(8); }
+    else if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else if (maxi <= 4) LN_BWD(bf16_t, 4); else LN_BWD(bf16_t, 8); }
     else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else if (maxi <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
 #undef LN_BWD
+#undef LN_BWDF
     KERNEL_CHECK();
     if (!direct)
         ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), deterministic ? 1 : std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);
     {   // class 8: dy, x (+ resid) in, dx (+ the dropout-masked copy) out, mean / rstd
-        const double lb = (double)rows * ((3.0 + (resid ? 1.0 : 0.0) + (dmask ? 1.0 : 0.0)) * E * dtype_size(dtype) + 8.0);
+        const double lb = (double)rows * ((3.0 + (resid ? 1.0 : 0.0) + (dmask ? 1.0 : 0.0) + (fz && fz->yout ? 1.0 : 0.0)) * E * dtype_size(dtype) + 8.0);
         PROF_STOP(8, s, lb, lb);
     }
     KERNEL_CHECK();

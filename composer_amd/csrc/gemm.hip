@@ -15,6 +15,7 @@
 // fp32 path (parity mode): v_mfma_f32_16x16x4_f32 = exact fp32 fma chains, 64x64x16 tile.
 #include "common.h"
 #include <vector>
+#include <mutex>
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -32,6 +33,8 @@ struct Epilogue {
     DropCfg drop;
     uint32_t* sched;       // persistent kernels: item counters of this launch (ItemPuller below); null = static striding
     uint32_t* sched_clear; // ... and the counter set the NEXT launch on this stream will draw from (zeroed by this one)
+    LnEpi ln;              // LayerNorm fused into the epilogue (compile-time kinds of the forward layout only, see common.h)
+    int rev;               // persistent 256x256 kernel: every XCD group walks its run of tiles from the END (see item_coords)
 };
 
 template <typename T, bool EXACT>
@@ -501,36 +504,161 @@ enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_AUX = 2, EPI_RESID = 3, EPI_GELU
 //   EPI_GELU_AUX : aux = acc + bias ; C = gelu(aux)                  c_fc forward
 //   EPI_RESID    : C = drop(acc (+ bias)) + resid                    both c_proj forward; dgrad c_attn (+ residual grad)
 //   EPI_GELUGRAD : C = acc * gelu'(aux)                              dgrad through the MLP activation
-template <int KIND, bool XOR_STG>
-__device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict__ C, int ldc, int row0, int col, float* stg,
-                                         int lane, const f32x4 (&acc)[8][4]) {
-    constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
-    constexpr int AHEAD = 2;
-    float b[8];
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor words (stride 0, range-checked): {base[31:0], base[47:32], num_records, flags}
+__device__ __forceinline__ v4i32 make_srd(const void* base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    v4i32 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xFFFFu));
+    d[2] = __builtin_amdgcn_readfirstlane((int)min(bytes, (int64_t)0x7FFFFFF0));
+    d[3] = 0x00020000;
+    return d;
+}
+// One 1-KiB LDS-DMA piece issued from inline asm, so hipcc's wait-count pass does not see a pending LDS write (it
+// would put s_waitcnt vmcnt(0) in front of the next ds_read and drain the pipeline).  M0 (LDS base) is written in
+// the same statement that reads it; completion is tracked by hand with counted s_waitcnt vmcnt(N).
+__device__ __forceinline__ void dma16(v4i32 srd, uint32_t lds_addr, int voff) {
+    // the "s" operands must BE in SGPRs: after control-flow merges the compiler may carry wave-uniform values in VGPRs
+    // and does not legalise inline-asm operands (readfirstlane folds away when the value already lives in an SGPR)
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
 #pragma unroll
-    for (int j = 0; j < 8; j++) b[j] = 0.f;
+    for (int i = 0; i < 4; i++) srd[i] = __builtin_amdgcn_readfirstlane(srd[i]);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(srd)
+                 : "memory", "m0");
+}
+
+// LNM (forward layout only): bit 0 = LayerNorm on the way IN (EPI_PLAIN / EPI_GELU_AUX: the fold of common.h's LnEpi -- the GEMM ran
+// on the raw rows and the gamma-scaled weight; EPI_RESID: the residual operand is LN(resid), rebuilt from the raw rows), NP =
+// 256-column segments of the LayerNorm input's rows; bit 1 = this tile's partial statistics of the OUTPUT rows go out (EPI_RESID):
+// per chunk the eight lanes that share a row merge their eight-column partials (three DPP steps), lane 0 of the eight parks the
+// wave's 64-column partial in `lstat` (LDS, [4 wave columns][256 tile rows]); the caller folds the four behind a barrier.
+//
+// What an epilogue READS from memory is requested by epi_prefetch(), which the 256x256 kernel calls BEFORE it issues the next
+// item's first k-slab: memory reads return in issue order, so a load issued behind the eight LDS-DMA pieces of a wave is only
+// delivered once they have landed (~2 us with the whole chip loading) -- the epilogue then starts after the slab it was meant
+// to overlap.  NPRE = operand chunks requested up front (16: all of them, the rest of the epilogue issues no load; 2: the rolling
+// form of the deep-pipeline kernels, which keep their stages in flight across the epilogue anyway).
+template <int KIND, int LNM, int NP>
+struct EpiPre {
+    float b[8];                 // bias
+    float lnA[8], lnB[8];       // fold: column sums of the gamma-scaled weight; residual rebuild: gamma, beta
+    bf16x8 opnd[16];            // residual / gelu' operand of every chunk
+    f32x2 pt[2][NP];            // LayerNorm on the way in: partial statistics of rows lane and lane + 64 of the wave's 128
+};
+template <int KIND>
+__device__ __forceinline__ bf16x8 epi_opnd(const Epilogue& ep, int row0, int col, int c, int rl) {
+    const bf16_t* __restrict__ src = KIND == EPI_RESID ? (const bf16_t*)ep.resid : (const bf16_t*)ep.aux;
+    const int lds = KIND == EPI_RESID ? ep.ldr : ep.ldaux;
+    const int row = row0 + c * 8 + rl;
+    // the 4E-wide pre-activation stream (0.5 GB per launch at B=128) is read non-temporally: 408 -> 380 us same-box;
+    // for the E-wide residual the hint measured neutral
+    if (KIND == EPI_GELUGRAD) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col));
+    return *reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col);
+}
+// Fold kinds (LayerNorm into c_attn / c_fc): what the epilogue reads -- the partial statistics of the wave's 128 rows (NP KiB,
+// contiguous), 64 floats of bias' and 64 of the column sums -- goes HBM -> LDS by DMA (no registers), issued by fold_dma() BEFORE
+// the next item's first k-slab: memory reads are delivered in issue order, so a load issued behind the eight slab pieces of a wave
+// only arrives once they have landed (~2 us with the whole chip loading).  (Measured: the same reads as ordinary loads inside the
+// epilogue, i.e. behind the slab, cost c_attn +43 us and c_fc +60 us per launch; as register loads in front of the slab they pushed
+// the kernel over its 256 registers and the slab's own address registers were spilled and reloaded between its pieces.)
+// LDS image per wave at `img`: [128 rows][NP] f32x2, then bias'[64], cs[64].
+#define FOLD_IMG_BYTES(NP) ((NP) * 1024 + 512)
+template <int NP>
+__device__ __forceinline__ void fold_dma(const Epilogue& ep, int row0, int col0, int lane, uint32_t img_lds) {
+    const v4i32 sp = make_srd(ep.ln.in_part + (int64_t)row0 * NP * 2, (int64_t)NP * 1024);
+#pragma unroll
+    for (int p = 0; p < NP; p++) dma16(sp, img_lds + p * 1024, p * 1024 + lane * 16);
+    const v4i32 sb = make_srd(ep.bias + col0, 256), sc = make_srd(ep.ln.cs + col0, 256);
+    if (lane < 16) {            // 16 lanes x 16 bytes each; the other lanes must not write (the next wave's image follows)
+        dma16(sb, img_lds + NP * 1024, lane * 16);
+        dma16(sc, img_lds + NP * 1024 + 256, lane * 16);
+    }
+}
+template <int KIND, int LNM, int NP, int NPRE>
+__device__ __forceinline__ void epi_prefetch(const Epilogue& ep, int row0, int col, int lane, EpiPre<KIND, LNM, NP>& pre,
+                                             const char* fold_img = nullptr) {
+    constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
+    constexpr bool LN_IN = (LNM & 1) != 0;
+    if constexpr (LN_IN && KIND != EPI_RESID) {
+        // from the wave's DMA image (fold_dma); the caller has waited for it
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int s = 0; s < NP; s++) pre.pt[h][s] = *reinterpret_cast<const f32x2*>(fold_img + ((h * 64 + lane) * NP + s) * 8);
+        const float* vb = reinterpret_cast<const float*>(fold_img + NP * 1024) + (lane & 7) * 8;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(vb), b1 = *reinterpret_cast<const f32x4*>(vb + 4);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(vb + 64), a1 = *reinterpret_cast<const f32x4*>(vb + 68);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pre.b[j] = b0[j]; pre.b[4 + j] = b1[j]; pre.lnA[j] = a0[j]; pre.lnA[4 + j] = a1[j]; }
+        return;
+    }
+    if constexpr (LN_IN) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const f32x2* __restrict__ pp = reinterpret_cast<const f32x2*>(ep.ln.in_part) + (int64_t)(row0 + h * 64 + lane) * NP;
+#pragma unroll
+            for (int s = 0; s < NP; s++) pre.pt[h][s] = pp[s];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) pre.b[j] = 0.f;
     if (KIND != EPI_GELUGRAD && ep.bias) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.bias + col), b1 = *reinterpret_cast<const f32x4*>(ep.bias + col + 4);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { b[j] = b0[j]; b[4 + j] = b1[j]; }
+        for (int j = 0; j < 4; j++) { pre.b[j] = b0[j]; pre.b[4 + j] = b1[j]; }
     }
+    if constexpr (LN_IN) {
+        const float* pa = KIND == EPI_RESID ? ep.ln.gamma : ep.ln.cs;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa + col), a1 = *reinterpret_cast<const f32x4*>(pa + col + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pre.lnA[j] = a0[j]; pre.lnA[4 + j] = a1[j]; }
+        if (KIND == EPI_RESID) {
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(ep.ln.beta + col), c1 = *reinterpret_cast<const f32x4*>(ep.ln.beta + col + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pre.lnB[j] = c0[j]; pre.lnB[4 + j] = c1[j]; }
+        }
+    }
+    if constexpr (LOADS) {
+        const int rl = lane >> 3;
+#pragma unroll
+        for (int c = 0; c < NPRE; c++) pre.opnd[c] = epi_opnd<KIND>(ep, row0, col, c, rl);
+    }
+}
+template <int KIND, bool XOR_STG, int LNM = 0, int NP = 1, int NPRE = 2>
+__device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict__ C, int ldc, int row0, int col, float* stg,
+                                         int lane, const f32x4 (&acc)[8][4], EpiPre<KIND, LNM, NP>& pre, f32x2* lstat = nullptr,
+                                         f32x2* lrow = nullptr) {
+    constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
+    constexpr bool LN_IN = (LNM & 1) != 0, LN_OUT = (LNM & 2) != 0;
     const int rl = lane >> 3;
     float cs[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) cs[j] = 0.f;
-    const bf16_t* __restrict__ src = KIND == EPI_RESID ? (const bf16_t*)ep.resid : (const bf16_t*)ep.aux;
-    const int lds = KIND == EPI_RESID ? ep.ldr : ep.ldaux;
-    bf16x8 opnd[16];
-    auto fetch = [&](int c) {
-        const int row = row0 + (c >> 1) * 16 + (c & 1) * 8 + rl;
-        // the 4E-wide pre-activation stream (0.5 GB per launch at B=128) is read non-temporally: 408 -> 380 us same-box;
-        // for the E-wide residual the hint measured neutral
-        if (KIND == EPI_GELUGRAD) opnd[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col));
-        else opnd[c] = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col);
-    };
-    if (LOADS) {
+    // row r of the wave's 128 keeps its (mean, rstd) at lrow[r * RS]: a strip of its own (residual kinds), or -- fold kinds -- in
+    // place over the first partial of the row in the DMA image (a lane overwrites only the two rows it has read itself)
+    constexpr int RS = (LN_IN && KIND != EPI_RESID) ? NP : 1;
+    if constexpr (LN_IN) {
+        // (mean, rstd) of the wave's 128 rows, once per item: lane l merges the partials of rows l and l + 64 (epi_prefetch) and
+        // parks the pair in LDS; every chunk then takes its row's pair with one ds_read_b64.
 #pragma unroll
-        for (int c = 0; c < AHEAD; c++) fetch(c);
+        for (int h = 0; h < 2; h++) {
+            float mu = 0.f;
+#pragma unroll
+            for (int s = 0; s < NP; s++) mu += pre.pt[h][s][0];
+            mu *= 1.0f / (float)NP;
+            float m2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < NP; s++) {
+                const float d = pre.pt[h][s][0] - mu;
+                m2 += pre.pt[h][s][1] + 256.0f * d * d;
+            }
+            lrow[(h * 64 + lane) * RS] = (f32x2){mu, __builtin_amdgcn_rsqf(m2 * (1.0f / (256.0f * (float)NP)) + ep.ln.eps)};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int c = 0; c < 16; c++) {
@@ -546,7 +674,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
                 }
             }
         }
-        if (LOADS && c + AHEAD < 16) fetch(c + AHEAD);
+        if (LOADS && c + NPRE < 16) pre.opnd[c + NPRE] = epi_opnd<KIND>(ep, row0, col, c + NPRE, rl);
         const int r16 = it * 8 + rl;
         f32x4 v0, v1;
         if (XOR_STG) {
@@ -559,9 +687,20 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         }
         const int row = row0 + i * 16 + r16;
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (KIND != EPI_GELUGRAD) {
+        float ln_mu = 0.f, ln_rs = 1.f;
+        if constexpr (LN_IN) {
+            const f32x2 st = lrow[(c * 8 + rl) * RS];   // the chunk's row inside the wave's 128: 8 c + rl
+            ln_mu = st[0];
+            ln_rs = st[1];
+        }
+        if (LN_IN && KIND != EPI_RESID) {
+            // rstd * acc - rstd*mean * colsum(gamma o W) + (beta.W + b)
+            const float mrs = ln_mu * ln_rs;
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] += b[j];
+            for (int j = 0; j < 8; j++) v[j] = fmaf(ln_rs, v[j], fmaf(-mrs, pre.lnA[j], pre.b[j]));
+        } else if (KIND != EPI_GELUGRAD) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += pre.b[j];
         }
         if (KIND == EPI_GELU_AUX) {
             if (ep.aux) {           // (inference passes do not keep the pre-activation: one output stream less)
@@ -576,23 +715,58 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
             for (int j = 0; j < 8; j++) v[j] = gelu_f<false>(v[j]);
         } else if (KIND == EPI_GELUGRAD) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)opnd[c][j]);
+            for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)pre.opnd[c][j]);
         } else if (KIND == EPI_RESID) {
             if (ep.drop.thr) {
                 const uint32_t rh = drop_row_hash(ep.drop, (uint32_t)row);
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = apply_drop_rc(ep.drop, rh, (uint32_t)(col + j), v[j]);
             }
+            if constexpr (LN_IN) {
+                // the residual operand is LayerNorm(raw row), rounded to bf16 like the stored tensor it replaces
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] += (float)opnd[c][j];
+                for (int j = 0; j < 8; j++) v[j] += (float)(bf16_t)(((float)pre.opnd[c][j] - ln_mu) * ln_rs * pre.lnA[j] + pre.lnB[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] += (float)pre.opnd[c][j];
+            }
         }
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = (bf16_t)v[j];
+        // Residual-stream rows of the fused block path are read next by a GEMM (the fold), not streamed by a LayerNorm kernel:
+        // default-policy stores there (inference forward of C2 7.88 -> 7.67 ms same-box; non-temporal everywhere else)
+#ifndef EPI_LNOUT_NT_STORE
+        if (LNM != 0 && KIND == EPI_RESID) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
+        else
+#endif
         __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col));
         if (ep.colsum) {
 #pragma unroll
             for (int j = 0; j < 8; j++) cs[j] += (float)o[j];
+        }
+        if constexpr (LN_OUT) {
+            // statistics of the STORED (rounded) values: what a LayerNorm kernel reading the tensor back would see
+            float f[8], sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { f[j] = (float)o[j]; sm += f[j]; }
+            float mn = sm * 0.125f, q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float d = f[j] - mn; q = fmaf(d, d, q); }
+            // Chan's update for equal counts n: mean = (ma + mb) / 2, M2 = M2a + M2b + (ma - mb)^2 * n / 2
+            {
+                const float pm = CMP_DPP_F(mn, 0xB1), pq = CMP_DPP_F(q, 0xB1), d = pm - mn;        // lane ^ 1: n = 8
+                mn = 0.5f * (mn + pm); q = (q + pq) + d * d * 4.0f;
+            }
+            {
+                const float pm = CMP_DPP_F(mn, 0x4E), pq = CMP_DPP_F(q, 0x4E), d = pm - mn;        // lane ^ 2: n = 16
+                mn = 0.5f * (mn + pm); q = (q + pq) + d * d * 8.0f;
+            }
+            {
+                const float pm = CMP_DPP_F(mn, 0x141), pq = CMP_DPP_F(q, 0x141), d = pm - mn;      // the other quad of the eight: n = 32
+                mn = 0.5f * (mn + pm); q = (q + pq) + d * d * 16.0f;
+            }
+            if ((lane & 7) == 0) lstat[i * 16 + r16] = (f32x2){mn, q};
         }
     }
     if (ep.colsum) {
@@ -892,7 +1066,10 @@ __device__ __forceinline__ bf16x8 h_frag(const char* img, int t16, int ks, int l
     }
 }
 
-template <bool A_KM, bool B_KM, bool SWAP, int EPI = EPI_GENERIC>
+// LayerNorm epilogues, in stage 1 behind the waves' staging areas: [4 wave columns][256 rows] f32x2 (the producers' 64-column
+// partials), then [8 waves][128 rows] f32x2 (the consumers' merged (mean, rstd) of their rows)
+#define LN_STAT_OFF (2 * H_IMG + 40960)
+template <bool A_KM, bool B_KM, bool SWAP, int EPI = EPI_GENERIC, int LNM = 0, int NP = 1>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
                                                                Epilogue ep, int ktiles_per_split, int nsplit, int tiles_n,
@@ -907,7 +1084,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
     auto item_coords = [&](int item, int& m0, int& n0, int& kt0, int& kt1) {
         // bijective XCD remap over items: the items one XCD works on are consecutive (shared A row panel in its L2)
         const int q = nitems >> 3, r = nitems & 7, x = item & 7;
-        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
+        // ep.rev: the group's run is walked from its END.  A kernel whose A operand is the tensor the PREVIOUS kernel wrote finds
+        // the rows that kernel wrote last still in this XCD's L2 / the Infinity Cache, and the rows it wrote first long evicted:
+        // reading in the producer's order misses everywhere (LRU under a stream larger than the cache), reading backwards hits on
+        // the tail.  The model alternates the direction from GEMM to GEMM (model.hip).
+        const int idx = ep.rev ? (q + (x < r ? 1 : 0)) - 1 - (item >> 3) : (item >> 3);
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
         // split-major: consecutive items (= one XCD's group) are the TILES of one K range, which share that range's A and B
         // panels through the XCD's L2.  (Tile-major -- the splits of one tile side by side -- gave an XCD sixteen disjoint K
         // ranges: no operand byte shared, 2.4x the algorithmic bytes at the L2's memory side in the wgrad launches,
@@ -1058,6 +1240,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         }
         // next item's first k-slab goes to stage 0 while this item's epilogue runs out of stage 1
         const int cm0 = m0, cn0 = n0;
+        // ... but what a fold epilogue reads from memory is requested FIRST (see fold_dma): in front of the slab, not behind it
+        constexpr bool FOLD = SWAP && (LNM & 1) != 0 && EPI != EPI_RESID && EPI != EPI_GENERIC;
+        const uint32_t fold_off = 2 * H_IMG + 8 * (16 * 68 * 4) + wave * FOLD_IMG_BYTES(NP);      // behind the waves' staging areas
+        if constexpr (FOLD) {
+            static_assert(8 * (16 * 68 * 4) + 8 * FOLD_IMG_BYTES(NP) <= 2 * H_IMG, "fold images must fit stage 1");
+            if (run) fold_dma<NP>(ep, cm0 + wm * 128, cn0 + wn * 64, lane, (uint32_t)(uintptr_t)(lds_char*)smem + fold_off);
+        }
         int next = pl.ctr ? __builtin_amdgcn_readfirstlane(*slot) : (int)(item + gridDim.x < nitems ? item + gridDim.x : -1);
         bool has_next = next >= 0;
         uint32_t pend2 = 0;
@@ -1078,7 +1267,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             float* stg = reinterpret_cast<float*>(smem + 2 * H_IMG) + wave * (16 * 68);   // stage 1: [16][68] floats per wave
             const int col = cn0 + wn * 64 + (lane & 7) * 8;
             if constexpr (EPI != EPI_GENERIC) {
-                epi_tile<EPI, false>(ep, (bf16_t*)C, ldc, cm0 + wm * 128, col, stg, lane, acc);
+                EpiPre<EPI, LNM, NP> pre;
+                if constexpr (FOLD) {
+                    // the wave's own fold image has landed once at most the slab's eight pieces (issued after it) are outstanding
+                    if (has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                epi_prefetch<EPI, LNM, NP, 2>(ep, cm0 + wm * 128, col, lane, pre, smem + fold_off);
+                epi_tile<EPI, false, LNM, NP, 2>(ep, (bf16_t*)C, ldc, cm0 + wm * 128, col, stg, lane, acc, pre,
+                                                  reinterpret_cast<f32x2*>(smem + LN_STAT_OFF) + wn * 256 + wm * 128,
+                                                  FOLD ? reinterpret_cast<f32x2*>(smem + fold_off)
+                                                       : reinterpret_cast<f32x2*>(smem + LN_STAT_OFF + 8192) + wave * 128);
             } else {
             const int rbase = cm0 + wm * 128 + (lane >> 3);
             float bias8[8];
@@ -1120,6 +1319,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                         if (row0 + 3 < M) atomicAdd(Cf + (int64_t)(row0 + 3) * ldc + col, acc[i][j][3]);
                     }
                 }
+        }
+        if constexpr ((LNM & 2) != 0) {
+            // the four wave columns' 64-column partials of every tile row -> the tile's 256-column partial (mean, M2) of that row.
+            // Read before the barrier at the top of the next item: its k-loop refills stage 1 only behind that one.
+            __syncthreads();
+            if (run && tid < 256) {
+                const f32x2* ls = reinterpret_cast<const f32x2*>(smem + LN_STAT_OFF);
+                const f32x2 p0 = ls[tid], p1 = ls[256 + tid], p2 = ls[512 + tid], p3 = ls[768 + tid];
+                const float mu = 0.25f * ((p0[0] + p1[0]) + (p2[0] + p3[0]));
+                const float d0 = p0[0] - mu, d1 = p1[0] - mu, d2 = p2[0] - mu, d3 = p3[0] - mu;
+                const float m2 = ((p0[1] + p1[1]) + (p2[1] + p3[1])) + 64.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                reinterpret_cast<f32x2*>(ep.ln.out_part)[(int64_t)(cm0 + tid) * (N >> 8) + (cn0 >> 8)] = (f32x2){mu, m2};
+            }
         }
         if (!has_next) {
             // own group exhausted: look at the other groups only now, behind this item's stores (a launch's tail)
@@ -1168,32 +1380,6 @@ __device__ __forceinline__ int p_sw(int r) {   // {0,2,3,1}[(r>>2)&3]
     return (0x78 >> (2 * q)) & 3;              // 0b01_11_10_00
 }
 __device__ __forceinline__ int pk_off(int r, int c) { return r * 64 + ((c ^ p_sw(r)) << 4); }
-
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-// raw buffer descriptor words (stride 0, range-checked): {base[31:0], base[47:32], num_records, flags}
-__device__ __forceinline__ v4i32 make_srd(const void* base, int64_t bytes) {
-    const uint64_t a = (uint64_t)base;
-    v4i32 d;
-    d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xFFFFu));
-    d[2] = __builtin_amdgcn_readfirstlane((int)min(bytes, (int64_t)0x7FFFFFF0));
-    d[3] = 0x00020000;
-    return d;
-}
-// One 1-KiB LDS-DMA piece issued from inline asm, so hipcc's wait-count pass does not see a pending LDS write (it
-// would put s_waitcnt vmcnt(0) in front of the next ds_read and drain the pipeline).  M0 (LDS base) is written in
-// the same statement that reads it; completion is tracked by hand with counted s_waitcnt vmcnt(N).
-__device__ __forceinline__ void dma16(v4i32 srd, uint32_t lds_addr, int voff) {
-    // the "s" operands must BE in SGPRs: after control-flow merges the compiler may carry wave-uniform values in VGPRs
-    // and does not legalise inline-asm operands (readfirstlane folds away when the value already lives in an SGPR)
-    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
-#pragma unroll
-    for (int i = 0; i < 4; i++) srd[i] = __builtin_amdgcn_readfirstlane(srd[i]);
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                 :
-                 : "s"(lds_addr), "v"(voff), "s"(srd)
-                 : "memory", "m0");
-}
 
 // PIECES 1-KiB pieces of one image, issued by this wave: pieces [first, first+count)
 template <bool KM>
@@ -1499,7 +1685,9 @@ __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __res
             if (NWM == 2) stg = reinterpret_cast<float*>(smem + (NST - 1) * STAGE) + wave * (16 * 64);
             const int col = cn0 + wn * 64 + (lane & 7) * 8;
             if constexpr (EPI != EPI_GENERIC) {
-                epi_tile<EPI, true>(ep, (bf16_t*)Cit, ldc, cm0 + wm * 128, col, stg, lane, acc);
+                EpiPre<EPI, 0, 1> pre;
+                epi_prefetch<EPI, 0, 1, 2>(ep, cm0 + wm * 128, col, lane, pre);
+                epi_tile<EPI, true, 0, 1, 2>(ep, (bf16_t*)Cit, ldc, cm0 + wm * 128, col, stg, lane, acc, pre);
             } else {
             const int rbase = cm0 + wm * 128 + (lane >> 3);
             float bias8[8];
@@ -1598,7 +1786,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad_group_kernel(int K, const W
 
 // dynamic-LDS opt-in, once per kernel
 static void allow_smem(const void* kern, size_t smem) {
+    static std::mutex mu;
     static std::vector<const void*> done;
+    std::lock_guard<std::mutex> lk(mu);
     if (std::find(done.begin(), done.end(), kern) != done.end()) return;
     (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     done.push_back(kern);
@@ -1611,13 +1801,14 @@ extern "C" int cmp_gemm_set_stamps(void* dev_buf) {
 template <bool A_KM, bool B_KM, int NWM, int NST>
 static bool launch_p4_cfg(hipStream_t s, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
                           void* C, int ldc, const Epilogue& ep, int per, int nsplit, int64_t slab_stride, int max_wgs) {
-    static bool attr_set = false;
     constexpr int BM = 128 * NWM;
     const size_t smem = (size_t)NST * (BM * P_BK * 2 + 256 * P_BK * 2) + 16;      // + the item slot
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    {
+        static std::once_flag attr_once;         // (per instantiation; two threads may launch through one library)
+        std::call_once(attr_once, [smem]() {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, true, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<A_KM, B_KM, false, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        });
     }
     const int tiles_n = cdiv(N, H_BN), ntiles = tiles_n * cdiv(M, BM);
     const int grid = std::min(ntiles * nsplit, NWM == 1 ? 2 * max_wgs : max_wgs);   // persistent: one (two) workgroups per CU in use
@@ -1681,6 +1872,15 @@ extern "C" int cmp_gemm_colsum_next(float* out) {
     t_colsum_next = out;
     return CMP_OK;
 }
+// One-shot, like cmp_gemm_colsum_next: the NEXT cmp_k_gemm of this thread carries a LayerNorm epilogue (common.h: LnEpi; the kernel-
+// level parity tests of the fused block path).  in_part / out_part: partial row statistics [rows][segments][2]; cs: fold; gamma, beta:
+// residual rebuild.  A launch that cannot carry it fails with CMP_ERR_INVALID.
+static thread_local LnEpi t_ln_next;
+extern "C" int cmp_gemm_ln_next(const float* in_part, int np, float eps, const float* cs, const float* gamma, const float* beta,
+                                float* out_part) {
+    t_ln_next = LnEpi{in_part, np, eps, cs, gamma, beta, out_part};
+    return CMP_OK;
+}
 static thread_local float* t_slab_ws = nullptr;       // split-K workspace for this thread's cmp_k_gemm calls
 static thread_local size_t t_slab_bytes = 0;
 extern "C" int cmp_gemm_set_workspace(void* ws, int64_t bytes) {
@@ -1692,12 +1892,13 @@ extern "C" int cmp_gemm_set_workspace(void* ws, int64_t bytes) {
 template <bool A_KM, bool B_KM>
 static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, const bf16_t* a, int lda, const bf16_t* b, int ldb,
                        void* C, int ldc, const Epilogue& ep, int per, int nsplit, int tiles_n, int ntiles) {
-    static bool attr_set = false;
     const size_t smem = 4 * H_IMG + 32;                                             // + the scheduler words
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    {
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [smem]() {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<A_KM, B_KM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        });
     }
     if constexpr (A_KM && B_KM) {        // the dgrad layout carries the compile-time epilogue kinds
         const int kind = epi_kind_of(ep, M, N, swap, false);
@@ -1705,6 +1906,20 @@ static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, 
             allow_smem((const void*)kern, smem);
             kern<<<grid, 512, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
         };
+        const int lnm = (ep.ln.in_part ? 1 : 0) | (ep.ln.out_part ? 2 : 0);
+        if (lnm) {
+            // LayerNorm-fused kinds (gemm_run has checked that the launch fits one): fold into c_attn / c_fc, statistics out of
+            // (and the rebuilt residual into) both c_proj
+#define LN_GO(KIND, LNM_, NP_) do { go(gemm_bf16_256_kernel<A_KM, B_KM, true, KIND, LNM_, NP_>); return true; } while (0)
+#define LN_NP(KIND, LNM_) do { if (ep.ln.np == 2) LN_GO(KIND, LNM_, 2); if (ep.ln.np == 3) LN_GO(KIND, LNM_, 3); } while (0)
+            if (kind == EPI_PLAIN && lnm == 1) LN_NP(EPI_PLAIN, 1);
+            if (kind == EPI_GELU_AUX && lnm == 1) LN_NP(EPI_GELU_AUX, 1);
+            if (kind == EPI_RESID && lnm == 3) LN_NP(EPI_RESID, 3);
+            if (kind == EPI_RESID && lnm == 2) LN_GO(EPI_RESID, 2, 1);
+#undef LN_NP
+#undef LN_GO
+            return false;       // unreachable after gemm_run's check
+        }
         if (kind == EPI_PLAIN) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_PLAIN>); return true; }
         if (kind == EPI_RESID) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_RESID>); return true; }
         if (kind == EPI_GELUGRAD) { go(gemm_bf16_256_kernel<A_KM, B_KM, true, EPI_GELUGRAD>); return true; }
@@ -1800,9 +2015,19 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
             (int64_t)K * q.lda * 2 >= 0x7FFFFFF0ll || (int64_t)K * q.ldb * 2 >= 0x7FFFFFF0ll)
             return CMP_OK;
     }
-    std::string key((const char*)probs, sizeof(WgradProblem) * nprob);
-    key.append((const char*)&K, sizeof(K));
-    key.append((const char*)&G, sizeof(G));
+    // the key is built field by field: WgradProblem has padding holes whose bytes are whatever the caller's stack held (a raw
+    // byte copy made every step look like new shapes: a rebuild, two stream syncs and an upload per block per step)
+    std::string key;
+    key.reserve((size_t)nprob * 48 + 8);
+    auto put = [&key](const void* p, size_t n) { key.append((const char*)p, n); };
+    for (int i = 0; i < nprob; i++) {
+        const WgradProblem& q = probs[i];
+        put(&q.A, sizeof(q.A)); put(&q.B, sizeof(q.B)); put(&q.C, sizeof(q.C));
+        const int v[5] = {q.lda, q.ldb, q.ldc, q.M, q.N};
+        put(v, sizeof(v));
+    }
+    put(&K, sizeof(K));
+    put(&G, sizeof(G));
     if (key != g->key) {
         struct Seg { int prob, m0, n0; };
         std::vector<Seg> tiles;
@@ -1877,6 +2102,7 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
         g->key = key;
         g->nitems = nitems;
         g->grid = std::min(nitems, G);
+        g->rebuilds += 1;
     }
     if (g->nitems == 0) return CMP_OK;                 // the cost model chose one launch per problem for these shapes
     Epilogue ep;
@@ -1887,11 +2113,12 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
     std::unique_lock<std::mutex> sched_lock;
     SchedWs* sched_used = nullptr;
     CHECK_SCHED(sched_next(s, ep, ex, sched_lock, &sched_used));
-    static bool attr_set = false;
     const size_t smem = (size_t)4 * (256 * P_BK * 2 + 256 * P_BK * 2) + 16;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
+    {
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [smem]() {
+            (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        });
     }
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < nprob; i++) {
@@ -1935,6 +2162,8 @@ extern "C" int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N,
     GemmExtra ex;
     ex.colsum = t_colsum_next;
     t_colsum_next = nullptr;
+    ex.ln = t_ln_next;
+    t_ln_next = LnEpi{};
     ex.slab_ws = t_slab_ws;
     ex.slab_bytes = t_slab_bytes;
     return gemm_run(stream, dtype, ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr, out_fp32, splitk,
@@ -1965,6 +2194,10 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
     ep.dbg_nostore = (flags & 64) ? 1 : 0;
     ep.colsum = nullptr;
     ep.sched = ep.sched_clear = nullptr;
+    ep.ln = ex.ln;
+    ep.rev = ex.rev ? 1 : 0;
+    const int lnm = (ex.ln.in_part ? 1 : 0) | (ex.ln.out_part ? 2 : 0);
+    bool ln_done = lnm == 0;         // a launch that asks for a LayerNorm epilogue must reach a kernel that has one
     float* colsum_out = ex.colsum;
     if (colsum_out) CMP_REQUIRE(!out_fp32 && splitk <= 1, "gemm: column sums need a plain (non split-K) output in the compute dtype");
     bool colsum_fused = false;
@@ -2044,6 +2277,18 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             const int g1 = std::min(ntiles * nsplit, max_wgs);
             const bool swap = !ep.atomic;
             ep.colsum = colsum_out;
+            if (lnm) {
+                const int kind = (!ta && tb) ? epi_kind_of(ep, M, N, swap, false) : EPI_GENERIC;
+                const bool in_ok = !(lnm & 1) || (ex.ln.np >= 2 && ex.ln.np <= 3 && (kind == EPI_RESID ? (ex.ln.gamma && ex.ln.beta && N == 256 * ex.ln.np)
+                                                                                                     : (ex.ln.cs && bias && K == 256 * ex.ln.np)));
+                const bool kind_ok = (lnm == 1 && (kind == EPI_PLAIN || kind == EPI_GELU_AUX)) || ((lnm & 2) && kind == EPI_RESID);
+                ln_done = kind_ok && in_ok && nsplit == 1 && !colsum_out;
+            }
+            if (!ln_done) {
+                cmp_set_error("gemm: this launch cannot carry the LayerNorm epilogue that was asked for (M=%d N=%d K=%d ta=%d tb=%d act=%d): "
+                              "bf16, A[M,K] . W^T[N,K], whole 256x256 tiles, 2 or 3 segments of 256 columns", M, N, K, ta, tb, act);
+                return CMP_ERR_INVALID;
+            }
             CHECK_SCHED(sched_next(s, ep, ex, sched_lock, &sched_used));
             if (!ta && !tb) colsum_fused = launch_256<true, false>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
             else if (!ta && tb) colsum_fused = launch_256<true, true>(s, g1, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, nsplit, tiles_n, ntiles);
@@ -2079,6 +2324,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
         }
     }
     if (sched_lock.owns_lock()) sched_lock.unlock();
+    CMP_REQUIRE(ln_done, "gemm: a LayerNorm epilogue was asked of a launch that went to a kernel without one (M=%d N=%d K=%d dtype=%d flags=%d)", M, N, K, dtype, flags);
     if (colsum_out && !colsum_fused) return cmp_k_colsum(stream, C, ldc, colsum_out, M, N, dtype);
     return CMP_OK;
 }

@@ -67,9 +67,16 @@ struct WDesc {      // one Conv1D weight in the flat buffers: [rows = in][cols =
     int rows, cols;
 };
 
+struct FoldDesc {   // one LayerNorm -> Conv1D pair of the fused block path (elementwise.hip: ln_fold_prep_kernel); offsets into the flat buffers
+    int64_t w_off, b_off, g_off, be_off;   // weight [rows][cols], bias [cols], gamma [rows], beta [rows]
+    int64_t out_off;                       // in the fold buffer: cs [cols], then bias' [cols]
+    int rows, cols;
+};
+
 struct LayerAct {
     void *u, *qkv, *att, *r, *n, *fc, *g;
     float *ln1_mean, *ln1_rstd, *ln2_mean, *ln2_rstd, *lse;
+    float *ln1_part = nullptr, *ln2_part = nullptr;    // fused block path: partial row statistics [tokens][E/256][2] of xs[i] and of r
 };
 
 struct cmp_model {
@@ -96,6 +103,17 @@ struct cmp_model {
     // at B=128); the refresh moves 38 MB (~12 us).
     bf16_t* ST = nullptr;
     void* wdesc = nullptr;     // device table of (offset, rows, cols) for the 4L matrices
+    // LayerNorm-fused block path (model.hip: ln_fused_ok): c_attn and c_fc run on the RAW residual rows and a gamma-scaled
+    // transposed shadow (in ST, at the weight's own offset), with the fold vectors cs / bias' of common.h's LnEpi in `lnfold`
+    // ([L] x {c_attn: cs[3E], bias'[3E]; c_fc: cs[4E], bias'[4E]}); refreshed with the transposed copies when a parameter moved.
+    void* wdesc_plain = nullptr;       // the 2L matrices that stay unscaled in that mode (both c_proj)
+    void* fdesc = nullptr;             // 2L FoldDesc
+    float* lnfold = nullptr;
+    int64_t fold_stride = 0;           // floats per block in lnfold; c_attn vectors at 0, c_fc vectors at 6E
+    int st_state = 0;                  // what ST holds: 0 nothing, 1 plain transposes, 2 the fused path's set
+    int64_t st_version = -1;           // ... of which param_version
+    bool fused_last = false;           // the forward pass whose activations are held took the fused path (its backward must too)
+    void* dmask3 = nullptr;            // second MLP-branch masked gradient (fused path: alternates with dmask from block to block)
     int64_t iterations = 0;
     int64_t param_version = 0;         // bumped whenever a parameter value changes (cmp_param_set, Adam): the decode state's
                                        // transposed weight copies are refreshed when it has moved
@@ -174,9 +192,20 @@ int embed_bwd_run(void* stream, const int32_t* ids, const void* dh, float* dwte,
                   int dtype, float p_drop, uint64_t seed, uint32_t rng_stream, int V, float* det_ws, size_t det_ws_bytes,
                   int sort_V = 0, int* sort_ws = nullptr, int64_t sort_ws_words = 0);
 int64_t embed_bwd_sort_ws_words(int64_t ntok, int V);
+struct LnBwdFused {     // layernorm_bwd_kernel<.., FUSED>: statistics from partials, the LayerNorm output written beside dx
+    const float* part = nullptr;   // [rows][np][2]
+    int np = 0;
+    float eps = 0.f;
+    const float* beta = nullptr;
+    void* yout = nullptr;          // xhat * gamma + beta (null: not wanted)
+};
 int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* resid, void* dx, float* dgamma, float* dbeta, void* ws, int rows, int E, int dtype, void* dmask,
-                      float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic);
+                      float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic, const LnBwdFused* fz = nullptr,
+                      bool keep_dmask = false);
+int embed_fwd_stats_run(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, float* part, int B, int T,
+                        int E, int pos0, float p_drop, uint64_t seed, uint32_t rng_stream);
+int ln_fold_prep_run(void* stream, const float* P, void* ST, float* fold, const void* desc_dev, int ndesc, int max_cols);
 int colsum_run(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype, float* det_ws, size_t det_ws_bytes);
 int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics);
 int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n);

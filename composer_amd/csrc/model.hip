@@ -331,7 +331,24 @@ static int model_create_fill(cmp_model* m, cmp_ctx* ctx, const cmp_model_cfg* cf
         }
         CHECK_RC(dev_alloc(m, &m->wdesc, wd.size() * sizeof(WDesc)));
         HIP_CHECK(hipMemcpyAsync(m->wdesc, wd.data(), wd.size() * sizeof(WDesc), hipMemcpyHostToDevice, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));      // wd is a local
+        // the LayerNorm-fused block path's tables (ln_fused_ok): the two c_proj weights keep plain transposes, c_attn / c_fc get the
+        // gamma-scaled ones + fold vectors
+        std::vector<WDesc> wp;
+        std::vector<FoldDesc> fd;
+        m->fold_stride = 2 * (int64_t)(3 * m->Ea + 4 * m->E);
+        for (int i = 0; i < m->L; i++) {
+            const LayerOff& o = m->lo[i];
+            wp.push_back({o.proj_w, m->Ea, m->E});
+            wp.push_back({o.pr_w, 4 * m->E, m->E});
+            fd.push_back({o.attn_w, o.attn_b, o.ln1_g, o.ln1_b, i * m->fold_stride, m->E, 3 * m->Ea});
+            fd.push_back({o.fc_w, o.fc_b, o.ln2_g, o.ln2_b, i * m->fold_stride + 6 * m->Ea, m->E, 4 * m->E});
+        }
+        CHECK_RC(dev_alloc(m, &m->wdesc_plain, wp.size() * sizeof(WDesc)));
+        CHECK_RC(dev_alloc(m, &m->fdesc, fd.size() * sizeof(FoldDesc)));
+        CHECK_RC(dev_alloc(m, &m->lnfold, (size_t)m->L * m->fold_stride * 4));
+        HIP_CHECK(hipMemcpyAsync(m->wdesc_plain, wp.data(), wp.size() * sizeof(WDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(m->fdesc, fd.data(), fd.size() * sizeof(FoldDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));      // wd, wp, fd are locals
     }
     CHECK_RC(dev_alloc(m, &m->metrics, sizeof(Metrics)));
     CHECK_RC(dev_alloc(m, &m->dp_metrics, 16));
@@ -528,6 +545,10 @@ static int ensure_workspace_fill(cmp_model* m, int B, int T) {
         CHECK_RC(dev_alloc(m, &a.ln2_mean, (size_t)M * 4));
         CHECK_RC(dev_alloc(m, &a.ln2_rstd, (size_t)M * 4));
         CHECK_RC(dev_alloc(m, &a.lse, (size_t)M * m->H * 4));
+        if (ln && m->ST && E % 256 == 0) {          // partial row statistics of the fused block path
+            CHECK_RC(dev_alloc(m, &a.ln1_part, (size_t)M * (E / 256) * 8));
+            CHECK_RC(dev_alloc(m, &a.ln2_part, (size_t)M * (E / 256) * 8));
+        }
     }
     CHECK_RC(dev_alloc(m, &m->hf, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->logits, (size_t)M * m->ldz * 4));
@@ -544,6 +565,7 @@ static int ensure_workspace_fill(cmp_model* m, int B, int T) {
     CHECK_RC(dev_alloc(m, &m->tmpE, (size_t)M * m->Ea * es));          // [M, E] gradients and the [M, Ea] attention-output gradient
     CHECK_RC(dev_alloc(m, &m->dmask, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->dmask2, (size_t)M * E * es));
+    CHECK_RC(dev_alloc(m, &m->dmask3, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->dfc, (size_t)M * 4 * E * es));
     CHECK_RC(dev_alloc(m, &m->dqkv, (size_t)M * 3 * m->Ea * es));
     {   // COMPOSER_DETERMINISTIC=1: no float atomics anywhere in the step -- split-K wgrads write per-split slabs and fold them
@@ -602,12 +624,46 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const bf16_t* __
         if (c < d.cols && r < d.rows) dst[(int64_t)c * d.rows + r] = tile[tx][ty + 8 * j];
     }
 }
-static int refresh_transposed_weights(cmp_model* m) {
+// fold: the LayerNorm-fused path's set (c_attn / c_fc scaled by the LayerNorm gammas, with their fold vectors).  Skipped when ST
+// already holds that set for the current parameter values (inference passes between parameter changes).
+static int refresh_transposed_weights(cmp_model* m, bool fold) {
     if (!m->ST) return CMP_OK;
+    const int want = fold ? 2 : 1;
+    if (m->st_state == want && m->st_version == m->param_version) return CMP_OK;
+    m->st_state = 0;
     const int maxtiles = std::max(cdiv(4 * m->E, 32) * cdiv(m->E, 32), cdiv(3 * m->Ea, 32) * cdiv(m->E, 32));   // [E,4E] or the head-padded [E,3Ea]
-    transpose_weights_kernel<<<dim3(maxtiles, 4 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc);
-    KERNEL_CHECK();
+    if (fold) {
+        transpose_weights_kernel<<<dim3(maxtiles, 2 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc_plain);
+        KERNEL_CHECK();
+        CHECK_RC(ln_fold_prep_run(m->ctx->stream, m->P, m->ST, m->lnfold, m->fdesc, 2 * m->L, 4 * m->E));
+    } else {
+        transpose_weights_kernel<<<dim3(maxtiles, 4 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc);
+        KERNEL_CHECK();
+    }
+    m->st_state = want;
+    m->st_version = m->param_version;
     return CMP_OK;
+}
+
+// The LayerNorm-fused block path (common.h: LnEpi): no ln_1 / ln_2 kernel runs in the forward pass, `u` and `n` are never
+// written by it.  Taken when every GEMM of a block reaches the persistent 256x256 kernel with whole tiles (bf16, E = 2 or 3
+// segments of 256 columns, no head padding, tokens a multiple of 256 and enough of them) and the call is a plain forward /
+// pass (no past, none of cmp_forward_ex's optional inputs).  COMPOSER_LN_FUSED=0 switches it off (A/B timing, tests).
+// Measured (profiles/r5_01_ln_fused.txt): the inference forward of C2 7.87 -> 7.65 ms; a TRAIN step loses 1.5-2 % (the two LayerNorm
+// backward kernels of a block write u / n instead of the forward kernels, and the fold GEMMs read a colder A operand than the
+// one a LayerNorm kernel has just written), so training passes take it only when COMPOSER_LN_FUSED=2 asks for it (tests).
+static bool ln_fused_ok(const cmp_model* m, int M, int past_len, bool training) {
+#ifdef COMPOSER_WGRAD_UNGROUPED
+    return false;
+#endif
+    const char* e = getenv("COMPOSER_LN_FUSED");
+    if (e && e[0] == '0') return false;
+    if (training && !(e && e[0] == '2')) return false;
+    if (!m->cfg.use_layer_norm || m->dtype != CMP_BF16 || m->slab || past_len) return false;
+    if (m->Ea != m->E || m->E % 256 || m->E < 512 || m->E > 768 || !m->act[0].ln1_part) return false;   // 2 or 3 segments (the fold images' LDS)
+    if (M % 256 || (int64_t)(M / 256) * (m->E / 256) < 192) return false;      // gemm_run's `big`: the N = E GEMMs too
+    if (m->fwd_pos_ids || m->fwd_type_ids || m->fwd_amask || m->fwd_probs_out) return false;
+    return true;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -623,16 +679,21 @@ static int colsum_any(cmp_model* m, const void* X, int ldx, float* out, int rows
 }
 static int ln_bwd(cmp_model* m, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                   const void* resid, void* dx, float* dgamma, float* dbeta, int rows, void* dmask, float* colsum, float p_drop,
-                  uint32_t rng_stream) {
+                  uint32_t rng_stream, const LnBwdFused* fz = nullptr) {
+    // (fused block path: every masked copy is written, dropout or not -- dx does not live until the weight gradients there)
     return layernorm_bwd_run(m->ctx->stream, dy, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, m->ln_ws, rows, m->E, m->dtype,
-                             dmask, colsum, p_drop, m->drop_seed(), rng_stream, m->slab != nullptr);
+                             dmask, colsum, p_drop, m->drop_seed(), rng_stream, m->slab != nullptr, fz, m->fused_last);
 }
 
+#define GEMM_REV (1 << 20)      // gemm() flag (model.hip only): GemmExtra::rev
 static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                 int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
-                int splitk, float p_drop, uint32_t rng_stream, int flags = 0, float* colsum = nullptr) {
+                int splitk, float p_drop, uint32_t rng_stream, int flags = 0, float* colsum = nullptr, const LnEpi* ln = nullptr) {
     const bool det = m->slab != nullptr;                               // COMPOSER_DETERMINISTIC=1
     GemmExtra ex;
+    if (ln) ex.ln = *ln;
+    ex.rev = (flags & GEMM_REV) != 0;
+    flags &= ~GEMM_REV;
     ex.colsum = det ? nullptr : colsum;                                // fused column sums are float atomics
     if (splitk > 1 && det) { ex.slab_ws = (float*)m->slab; ex.slab_bytes = (size_t)m->slab_bytes; }
     ex.role = m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1);         // forward announces 0; backward: A^T = wgrad, else dgrad
@@ -689,13 +750,46 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
     const int Tp = past_len, Tt = past_len + T;
     m->lastB = B; m->lastT = Tt; m->last_past = Tp;
     m->fwd_gen += 1;
-    CHECK_RC(embed_fwd_run(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, Tp, dt, pr, m->drop_seed(),
-                           drop_stream(step, 0, 0), m->fwd_pos_ids, m->fwd_type_ids));
-    CHECK_RC(refresh_transposed_weights(m));
+    const bool fused = ln_fused_ok(m, M, Tp, training);
+    m->fused_last = fused;
+    if (fused)
+        CHECK_RC(embed_fwd_stats_run(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], m->act[0].ln1_part, B, T, E, 0, pr,
+                                     m->drop_seed(), drop_stream(step, 0, 0)));
+    else
+        CHECK_RC(embed_fwd_run(s, x_dev, m->P + m->off_wte, m->P + m->off_wpe, m->xs[0], B, T, E, Tp, dt, pr, m->drop_seed(),
+                               drop_stream(step, 0, 0), m->fwd_pos_ids, m->fwd_type_ids));
+    CHECK_RC(refresh_transposed_weights(m, fused));
     // Conv1D weight operand of the forward GEMMs: [in,out] as stored (fp32 mode), or the transposed bf16 copy (tb = 1)
     const bool wt = m->ST != nullptr;
     auto W = [&](int64_t off) { return wt ? (const void*)(m->ST + off) : m->w(off); };
-    for (int i = 0; i < m->L; i++) {
+    static const int alt_mode = [] { const char* e = getenv("COMPOSER_GEMM_ALT"); return e ? atoi(e) : 0; }();
+    const int RV[4] = {alt_mode == 2 ? GEMM_REV : 0, alt_mode == 1 ? GEMM_REV : 0, alt_mode == 2 ? GEMM_REV : 0, alt_mode == 1 ? GEMM_REV : 0};
+    for (int i = 0; fused && i < m->L; i++) {
+        // transformer.py:574-597 with both LayerNorms inside the GEMM epilogues (common.h: LnEpi)
+        const LayerOff& o = m->lo[i];
+        LayerAct& a = m->act[i];
+        const float* fold = m->lnfold + i * m->fold_stride;
+        LnEpi l;
+        l.in_part = a.ln1_part; l.np = E / 256; l.eps = m->cfg.ln_eps; l.cs = fold;
+        CHECK_RC(gemm(m, 0, 1, M, 3 * E, E, m->xs[i], E, W(o.attn_w), E, a.qkv, 3 * E, fold + 3 * E, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
+                      0, RV[0], nullptr, &l));                                        // qkv = ln_1(x).Wattn + b   :583-584, 417
+        CHECK_RC(attn_fwd_run(s, a.qkv, a.att, a.lse, B, Tt, m->H, m->D, attn_scale(m), dt, pa, m->drop_seed(), drop_stream(step, i, 1),
+                              nullptr));
+        l = LnEpi();
+        l.in_part = a.ln1_part; l.np = E / 256; l.eps = m->cfg.ln_eps; l.gamma = m->P + o.ln1_g; l.beta = m->P + o.ln1_b;
+        l.out_part = a.ln2_part;
+        CHECK_RC(gemm(m, 0, 1, M, E, E, a.att, E, W(o.proj_w), E, a.r, E, m->P + o.proj_b, 0, nullptr, 0, m->xs[i], E, 0, 1, pr,
+                      drop_stream(step, i, 2), RV[1], nullptr, &l));                  // r = ln_1(x) + dropout(proj)  :587
+        l = LnEpi();
+        l.in_part = a.ln2_part; l.np = E / 256; l.eps = m->cfg.ln_eps; l.cs = fold + 6 * E;
+        CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, a.r, E, W(o.fc_w), E, a.g, 4 * E, fold + 10 * E, 1, training ? a.fc : nullptr, 4 * E, nullptr,
+                      0, 0, 1, 0.f, 0, RV[2], nullptr, &l));                          // g = gelu(ln_2(r).Wfc + b)    :591, 504
+        l = LnEpi();
+        if (i + 1 < m->L) l.out_part = m->act[i + 1].ln1_part;                        // (ln_f runs as a kernel: it needs no partials)
+        CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, a.g, 4 * E, W(o.pr_w), 4 * E, m->xs[i + 1], E, m->P + o.pr_b, 0, nullptr, 0, a.r, E, 0, 1, pr,
+                      drop_stream(step, i, 3), RV[3], nullptr, l.out_part ? &l : nullptr));   // x = r + dropout(mlp)  :594
+    }
+    for (int i = 0; !fused && i < m->L; i++) {
         const LayerOff& o = m->lo[i];
         LayerAct& a = m->act[i];
         if (ln)   // transformer.py:583-584 -- the LN output REPLACES the residual stream
@@ -809,6 +903,13 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                     m->G + m->off_lnf_g, m->G + m->off_lnf_b, M, m->dmask, m->G + m->lo[m->L - 1].pr_b, pr,
                     drop_stream(step, m->L - 1, 3)));
     bool dmo_ready = true;      // dmask / pr_b of the current layer already produced
+    // The LayerNorm-fused block path (model_forward): the forward pass wrote neither u = ln_1(x) nor n = ln_2(r) and kept their
+    // statistics as partials.  The two LayerNorm backward kernels of a block merge the partials and write u / n beside dx -- only
+    // the block's weight-gradient launch reads them, so that launch moves behind ln_1's backward; by then ln_1's backward has
+    // produced the NEXT block's MLP masked gradient, hence two alternating buffers for it.
+    const bool fused = m->fused_last;
+    void* const dmk[2] = {m->dmask, m->dmask3};
+    int cur = 0;
     if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total, lr));
     // The four Conv1D weight gradients of a block contract over the same M tokens: with LayerNorm, bf16 and the atomic
     // (non-deterministic) split-K form they go out as ONE grouped launch behind the block's attention backward (gemm.hip:
@@ -819,6 +920,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
 #else
     const bool grouped = ln && dt == CMP_BF16 && !m->slab;
 #endif
+    CMP_REQUIRE(!fused || grouped, "backward: the fused block path needs the grouped weight-gradient order");
     if (grouped && (int)m->wgrad_groups.size() != m->L) m->wgrad_groups.resize(m->L);
     for (int i = m->L - 1; i >= 0; i--) {
         const LayerOff& o = m->lo[i];
@@ -826,10 +928,14 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         bool group_now = grouped;
         // ---- MLP: x_out = r + dropout(gelu(n.Wfc+b).Wpr+b)
         const void* dmo = m->dx;
-        if (pr > 0.f) {
+        if (fused) {
+            dmo = dmk[cur];             // (also without dropout: dx is overwritten before the weight gradients read it)
+        } else if (pr > 0.f) {
             if (!dmo_ready) CHECK_RC(drop_apply(m, m->dx, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 3)));
             dmo = m->dmask;
         }
+        LnBwdFused fz;
+        fz.np = E / 256; fz.eps = m->cfg.ln_eps;
         auto wgrad = [&](int Mw, int Nw, const void* A, int lda, const void* Bm, int ldb, float* Cw) {
             return gemm(m, 1, 0, Mw, Nw, M, A, lda, Bm, ldb, Cw, Nw, nullptr, 0, nullptr, 0, nullptr, 0, 1, std::max(2, wgrad_splits(M, Mw, Nw)), 0.f, 0);
         };
@@ -842,15 +948,18 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->tmpE, E, nullptr, 0, nullptr, 0, nullptr,
                           0, 0, 1, 0.f, 0));                                       // dn
+            fz.part = a.ln2_part; fz.beta = m->P + o.ln2_b; fz.yout = a.n;
             CHECK_RC(ln_bwd(m, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr, m->G + o.ln2_g, m->G + o.ln2_b, M,
-                            dao_mask, m->G + o.proj_b, pr, drop_stream(step, i, 2)));   // dr = dx + LN2'(dn); dao, b_proj grad
+                            dao_mask, m->G + o.proj_b, pr, drop_stream(step, i, 2), fused ? &fz : nullptr));   // dr = dx + LN2'(dn); dao, b_proj grad
         } else {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->dr, E, nullptr, 0, nullptr, 0, m->dx, E,
                           0, 1, 0.f, 0));                                          // dr = dx + dn
         }
         // ---- attention: r = u + dropout(att.Wproj+b)
         const void* dao = m->dr;
-        if (pr > 0.f) {
+        if (fused) {
+            dao = dao_mask;
+        } else if (pr > 0.f) {
             if (!ln) CHECK_RC(drop_apply(m, m->dr, m->dmask, (int64_t)M * E, pr, drop_stream(step, i, 2)));
             dao = dao_mask;
         }
@@ -862,7 +971,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, attn_scale(m),
                               dt, pa, m->drop_seed(), drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b));   // b_attn grad = column sums of dqkv
         if (det) CHECK_RC(colsum_det(m, m->dqkv, 3 * Ea, m->G + o.attn_b, M, 3 * Ea));
-        if (group_now) {
+        auto group_launch = [&]() -> int {
             const WgradProblem wp[4] = {
                 {a.g, 4 * E, dmo, E, m->G + o.pr_w, E, 4 * E, E},                  // dWpr   = g^T . dmo
                 {a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, E, 4 * E},           // dWfc   = n^T . dfc
@@ -881,16 +990,26 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                 CHECK_RC(wgrad(Ea, E, a.att, Ea, dao, E, m->G + o.proj_w));
                 CHECK_RC(wgrad(E, 3 * Ea, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w));
             }
-        } else {
+            return CMP_OK;
+        };
+        if (group_now && !fused) {
+            CHECK_RC(group_launch());
+        } else if (!group_now) {
             CHECK_RC(wgrad(E, 3 * Ea, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w));
         }
         if (ln) {
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * Ea, m->dqkv, 3 * Ea, m->w(o.attn_w), 3 * Ea, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
                           E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T
             // dx_in = LN1'(du): no skip connection around LN1; feeds layer i-1's MLP branch (or the embedding for i = 0)
+            fz.part = a.ln1_part; fz.beta = m->P + o.ln1_b; fz.yout = a.u;
+            void* const next_mask = fused ? dmk[cur ^ 1] : m->dmask;
             CHECK_RC(ln_bwd(m, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx, m->G + o.ln1_g,
-                            m->G + o.ln1_b, M, i > 0 ? m->dmask : nullptr, i > 0 ? m->G + m->lo[i - 1].pr_b : nullptr, pr,
-                            drop_stream(step, i > 0 ? i - 1 : 0, 3)));
+                            m->G + o.ln1_b, M, i > 0 ? next_mask : nullptr, i > 0 ? m->G + m->lo[i - 1].pr_b : nullptr, pr,
+                            drop_stream(step, i > 0 ? i - 1 : 0, 3), fused ? &fz : nullptr));
+            if (fused) {
+                CHECK_RC(group_launch());          // g^T.dmo, n^T.dfc, att^T.dao, u^T.dqkv -- u and n as just written
+                cur ^= 1;
+            }
             dmo_ready = true;
         } else {
             dmo_ready = false;
@@ -978,6 +1097,17 @@ extern "C" int cmp_dp_stats(cmp_model* m, int reset, int64_t* steps, double* exp
     if (bytes_per_step) *bytes_per_step = m->ctx->comm ? m->dp_bytes_step : 0;
     if (msgs_per_step) *msgs_per_step = m->ctx->comm ? m->dp_msgs_step : 0;
     if (reset) { m->dp_steps = 0; m->dp_folded = 0; m->dp_exposed_ms = 0.0; }
+    return CMP_OK;
+}
+
+extern "C" int cmp_model_path_info(cmp_model* m, int* fused, int64_t* wgrad_table_builds) {
+    CMP_REQUIRE(m, "model_path_info: null model");
+    if (fused) *fused = m->fused_last ? 1 : 0;
+    if (wgrad_table_builds) {
+        int64_t n = 0;
+        for (const WgradGroup& g : m->wgrad_groups) n += g.rebuilds;
+        *wgrad_table_builds = n;
+    }
     return CMP_OK;
 }
 

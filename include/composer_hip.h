@@ -250,6 +250,38 @@ int cmp_k_gemm(void* stream, int dtype, int ta, int tb, int M, int N, int K,
  * below 2 GiB.  The model's backward pass uses this launch in bf16 mode. */
 int cmp_k_wgrad_group(void* stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                       float* const* C, const int* ldc, const int* M, const int* N, int K);
+/* ---- LayerNorm folded into the block's GEMM epilogues (the fused block path of the bf16 train / inference forward) -----------
+ * Replaces the stand-alone tf.keras LayerNormalization calls of DecoderBlock.call (transformer.py:583-584 ln_1, :591 ln_2; layers
+ * built at :551,563) for large batches: no LayerNorm kernel runs in the forward pass.  Row statistics travel as PARTIALS, fp32
+ * [rows][E/256][2] = (mean, M2 = sum of squared deviations from that mean) of every 256-column segment of a row, merged with
+ * Chan's update by the consumer (never a sum of squares).
+ *   cmp_k_embed_fwd_stats: cmp_k_embed_fwd (bf16) that also leaves the partials of the rows it wrote (SharedTokenEmbedding +
+ *     position embedding, transformer.py:786-794, feeding block 0's ln_1).  E a multiple of 256.
+ *   cmp_k_ln_fold_prep: weight side of  LN(x).W + b = rstd*(x.(gamma o W)) - rstd*mean*colsum(gamma o W) + (beta.W + b):
+ *     W fp32 [E,N] (Conv1D weight, transformer.py:184-189), bias [N], gamma / beta [E] -> WT bf16 [N,E] = (gamma o W)^T,
+ *     cs[N] = column sums of the ROUNDED WT, bias_out[N] = bias + beta.W.  E, N multiples of 32.
+ *   cmp_gemm_ln_next: one-shot, the NEXT cmp_k_gemm of this thread carries a LayerNorm epilogue -- in_part (+ np = E/256 in
+ *     2..3, eps): statistics of the rows of A (fold: cs given; the GEMM's B operand is WT and its bias is bias_out) or of the
+ *     rows of `resid` (gamma, beta given: the residual operand becomes LN(resid), transformer.py:587); out_part: the partials of
+ *     the OUTPUT rows are written (residual epilogues).  bf16, ta=0, tb=1, M and N multiples of 256, and a shape that reaches the
+ *     persistent 256x256 kernel (CMP_GEMM_TILE256 forces it); anything else fails with CMP_ERR_INVALID.
+ *   cmp_k_layernorm_bwd_parts: cmp_k_layernorm_bwd_fused (bf16) with the statistics taken from partials and the LayerNorm OUTPUT
+ *     yout = xhat*gamma + beta written beside dx (the weight-gradient GEMM of the consuming Conv1D is its only reader); dmask
+ *     (when given) is written whatever p_drop is. */
+int cmp_k_embed_fwd_stats(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, float* part,
+                          int B, int T, int E, int pos0, float p_drop, uint64_t seed, uint32_t rng_stream);
+int cmp_k_ln_fold_prep(void* stream, const float* W, const float* bias, const float* gamma, const float* beta, void* WT,
+                       float* cs, float* bias_out, int E, int N);
+int cmp_gemm_ln_next(const float* in_part, int np, float eps, const float* cs, const float* gamma, const float* beta,
+                     float* out_part);
+int cmp_k_layernorm_bwd_parts(void* stream, const void* dy, const void* x, const float* gamma, const float* beta,
+                              const float* part, float eps, const void* resid, void* dx, void* yout, float* dgamma,
+                              float* dbeta, void* ws, int rows, int E, void* dmask, float* colsum, float p_drop,
+                              uint64_t seed, uint32_t rng_stream);
+/* Diagnostics of the model's last passes: fused = 1 when the last forward pass took the LayerNorm-fused block path;
+ * wgrad_table_builds = item tables of the grouped weight-gradient launches built so far (a steady train loop builds one per
+ * decoder block, once). */
+int cmp_model_path_info(cmp_model* m, int* fused, int64_t* wgrad_table_builds);
 /* Registers a device workspace for split-K reductions: with it, split-K launches write per-split fp32 partial tiles and
  * fold them in a fixed order (reproducible, no float atomics); without it (or if too small: splitk*M*N*4 bytes) they
  * accumulate with f32 atomics.  flags & 128 forces the atomic path. */

@@ -1,0 +1,328 @@
+"""-m gpu: the LayerNorm-fused block path (round 5).
+
+For large bf16 batches no LayerNorm kernel runs inside the decoder blocks' forward pass (DecoderBlock.call,
+transformer.py:574-597; LayerNormalization layers :551,563): the row statistics travel as partials (mean, M2 per 256-column
+segment) written by the producing epilogue, ln_1 / ln_2 are folded into the c_attn / c_fc GEMMs
+(LN(x).W + b = rstd*(x.(gamma o W)) - rstd*mean*colsum(gamma o W) + (beta.W + b)), the attention c_proj epilogue rebuilds
+ln_1(x) for its residual operand, and the LayerNorm backward kernels write u = ln_1(x) / n = ln_2(r) for the weight gradients.
+
+Every new kernel form against float64 (the oracle's formulas: O.layernorm_fwd / O.gelu / O.dropout_keep_rows), then the model:
+the fused path against the unfused one and against the bf16-rounding oracle at a batch both paths can run.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+FP32, BF16 = 0, 1
+V = 390
+EPS = 1e-5
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from composer_amd import _lib
+    l = _lib.load()
+    _lib.require_gpu()
+    return l
+
+
+def ck(lib, rc):
+    assert rc == 0, lib.cmp_last_error().decode()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ALIVE = []          # device tensors handed to the library as raw pointers stay referenced until the test is over
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    torch.cuda.synchronize()
+    _ALIVE.clear()
+
+
+def bf(a):
+    _ALIVE.append(torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).cuda().contiguous())
+    return _ALIVE[-1]
+
+
+def f32(a):
+    _ALIVE.append(torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda().contiguous())
+    return _ALIVE[-1]
+
+
+def parts_of(x64):
+    """(mean, M2) of every 256-column segment of every row: float64 [rows, E/256, 2]."""
+    rows, E = x64.shape
+    seg = x64.reshape(rows, E // 256, 256)
+    mu = seg.mean(-1)
+    return np.stack([mu, ((seg - mu[..., None]) ** 2).sum(-1)], -1)
+
+
+def ln64(x64, gamma, beta):
+    mu = x64.mean(-1, keepdims=True)
+    var = ((x64 - mu) ** 2).mean(-1, keepdims=True)
+    return (x64 - mu) / np.sqrt(var + EPS) * gamma + beta
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30)
+
+
+# --------------------------------------------------------------------------------------------- embedding + partials
+@pytest.mark.parametrize("E,p", [(512, 0.0), (768, 0.1), (1024, 0.1), (256, 0.0)])
+def test_embedding_forward_leaves_the_rows_partial_statistics(lib, E, p):
+    B, T, W = 3, 40, 64
+    rng = np.random.default_rng(E)
+    ids = torch.as_tensor(rng.integers(0, V, (B, T)).astype(np.int32)).cuda()
+    wte, wpe = f32(rng.normal(0, 1.0, (V, E)) + 3.0), f32(rng.normal(0, 1.0, (W, E)))
+    ref = torch.zeros(B * T, E, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros_like(ref)
+    part = torch.zeros(B * T, E // 256, 2, device="cuda")
+    ck(lib, lib.cmp_k_embed_fwd(stream(), P(ids), P(wte), P(wpe), P(ref), B, T, E, 5, BF16, p, 11, 3))
+    ck(lib, lib.cmp_k_embed_fwd_stats(stream(), P(ids), P(wte), P(wpe), P(out), P(part), B, T, E, 5, p, 11, 3))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)                                   # the same rows, bit for bit (same mask, same rounding)
+    want = parts_of(out.double().cpu().numpy())
+    got = part.double().cpu().numpy()
+    assert np.abs(got[..., 0] - want[..., 0]).max() < 1e-5 * (1 + np.abs(want[..., 0]).max())
+    assert rel(got[..., 1], want[..., 1]) < 1e-5
+
+
+# --------------------------------------------------------------------------------------------- weight side of the fold
+@pytest.mark.parametrize("E,N", [(512, 1536), (768, 3072), (1024, 1024), (64, 96)])
+def test_fold_prep_scales_transposes_and_sums(lib, E, N):
+    rng = np.random.default_rng(E + N)
+    W = rng.normal(0, 0.05, (E, N)).astype(np.float32)
+    b = rng.normal(0, 0.1, N).astype(np.float32)
+    g = (1 + 0.3 * rng.normal(size=E)).astype(np.float32)
+    be = rng.normal(0, 0.2, E).astype(np.float32)
+    WT = torch.zeros(N, E, dtype=torch.bfloat16, device="cuda")
+    cs, bo = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    ck(lib, lib.cmp_k_ln_fold_prep(stream(), P(f32(W)), P(f32(b)), P(f32(g)), P(f32(be)), P(WT), P(cs), P(bo), E, N))
+    torch.cuda.synchronize()
+    want = torch.as_tensor(g[:, None] * W).to(torch.bfloat16).T.contiguous()         # fp32 product, one rounding
+    assert torch.equal(WT.cpu(), want)
+    assert rel(cs.cpu().numpy(), want.double().numpy().sum(1)) < 2e-6
+    assert rel(bo.cpu().numpy(), b.astype(np.float64) + be.astype(np.float64) @ W.astype(np.float64)) < 2e-6
+
+
+# --------------------------------------------------------------------------------------------- GEMM epilogues
+def _gemm_ln(lib, A, WT, M, N, K, bias, act, aux, resid, p, ln, out_dtype=torch.bfloat16):
+    Cm = torch.zeros(M, N, dtype=out_dtype, device="cuda")
+    ck(lib, lib.cmp_gemm_ln_next(*ln))
+    ck(lib, lib.cmp_k_gemm(stream(), BF16, 0, 1, M, N, K, P(A), K, P(WT), K, P(Cm), N, P(bias), act, P(aux), N if aux is not None else 0,
+                           P(resid), N if resid is not None else 0, 0, 1, p, 21, 9, 8))
+    torch.cuda.synchronize()
+    return Cm
+
+
+@pytest.mark.parametrize("E", [512, 768])
+@pytest.mark.parametrize("offset", [0.0, 24.0])          # rows with |mean| >> sigma: the fold subtracts two large terms
+@pytest.mark.parametrize("act", [0, 1])
+def test_fold_epilogue_is_layernorm_then_conv1d(lib, E, offset, act):
+    """c_attn / c_fc of the fused path: the GEMM runs on the RAW rows and the gamma-scaled weight; the epilogue applies the row
+    statistics.  Reference: float64 LayerNorm of the same bf16 rows, times the fp32 weight, (+ GELU, pre-activation stored)."""
+    M, N = 512, 768
+    rng = np.random.default_rng(E + int(offset) + act)
+    x = bf(rng.normal(offset, 1.0, (M, E)) * (1 + rng.random((M, 1))))
+    W = rng.normal(0, 0.05, (E, N)).astype(np.float32)
+    b = rng.normal(0, 0.1, N).astype(np.float32)
+    g = (1 + 0.3 * rng.normal(size=E)).astype(np.float32)
+    be = rng.normal(0, 0.2, E).astype(np.float32)
+    WT = torch.zeros(N, E, dtype=torch.bfloat16, device="cuda")
+    cs, bo = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    ck(lib, lib.cmp_k_ln_fold_prep(stream(), P(f32(W)), P(f32(b)), P(f32(g)), P(f32(be)), P(WT), P(cs), P(bo), E, N))
+    x64 = x.double().cpu().numpy()
+    part = f32(parts_of(x64))
+    aux = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda") if act else None
+    out = _gemm_ln(lib, x, WT, M, N, E, bo, act, aux, None, 0.0, (P(part), E // 256, EPS, P(cs), None, None, None))
+    pre = ln64(x64, g.astype(np.float64), be.astype(np.float64)) @ W.astype(np.float64) + b
+    # tight: the epilogue's own formula in float64 on the ROUNDED scaled weight (what remains is fp32 accumulation + the bf16 store)
+    mu, var = x64.mean(-1, keepdims=True), x64.var(-1, keepdims=True)
+    rs = 1 / np.sqrt(var + EPS)
+    wt64 = WT.double().cpu().numpy()
+    exact = rs * (x64 @ wt64.T) - rs * mu * wt64.sum(1) + bo.double().cpu().numpy()
+    if act:
+        assert rel(aux.double().cpu().numpy(), exact) < 6e-3
+        assert rel(aux.double().cpu().numpy(), pre) < 1.2e-2
+        exact, pre = O.gelu(exact), O.gelu(pre)
+    assert rel(out.double().cpu().numpy(), exact) < 6e-3
+    assert rel(out.double().cpu().numpy(), pre) < 1.2e-2               # ... and it IS LayerNorm + Conv1D within the bf16 weight rounding
+
+
+@pytest.mark.parametrize("E", [512, 768])
+@pytest.mark.parametrize("rebuild", [False, True])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_residual_epilogue_emits_partials_and_rebuilds_ln1(lib, E, rebuild, p):
+    """Both c_proj epilogues: C = dropout(A.W + b) + residual, the residual being a stored tensor (mlp c_proj) or ln_1 of the raw
+    block input rebuilt from its partials (attention c_proj); the partial statistics of C's rows go out."""
+    M, K = 768, 512
+    rng = np.random.default_rng(E + rebuild + int(10 * p))
+    A = bf(rng.normal(0, 1.0, (M, K)))
+    W = bf(rng.normal(0, 0.05, (E, K)))                              # stored [N, K]
+    b = f32(rng.normal(0, 0.1, E))
+    r = bf(rng.normal(2.0, 1.5, (M, E)))
+    g = (1 + 0.3 * rng.normal(size=E)).astype(np.float32)
+    be = rng.normal(0, 0.2, E).astype(np.float32)
+    r64 = r.double().cpu().numpy()
+    pin = f32(parts_of(r64))
+    pout = torch.full((M, E // 256, 2), -7.0, device="cuda")
+    ln = (P(pin), E // 256, EPS, None, P(f32(g)), P(f32(be)), P(pout)) if rebuild else (None, 0, 0.0, None, None, None, P(pout))
+    out = _gemm_ln(lib, A, W, M, E, K, b, 0, None, r, p, ln)
+    acc = A.double().cpu().numpy() @ W.double().cpu().numpy().T + b.double().cpu().numpy()
+    if p > 0:
+        keep = O.dropout_keep_rows(21, 9, M, E, p)
+        acc = np.where(keep, acc / (1 - p), 0.0)
+    res = ln64(r64, g.astype(np.float64), be.astype(np.float64)) if rebuild else r64
+    if rebuild:
+        res = torch.as_tensor(res).to(torch.bfloat16).double().numpy()   # the stored ln_1 output it replaces is bf16
+    want = acc + res
+    got = out.double().cpu().numpy()
+    assert rel(got, want) < 8e-3
+    sp = parts_of(got)                                                # statistics of the STORED rows
+    gp = pout.double().cpu().numpy()
+    assert np.abs(gp[..., 0] - sp[..., 0]).max() < 2e-5 * (1 + np.abs(sp[..., 0]).max())
+    assert rel(gp[..., 1], sp[..., 1]) < 2e-5
+
+
+def test_a_launch_that_cannot_carry_the_epilogue_fails_loudly(lib):
+    M, N, K = 256, 256, 512
+    A, W = bf(np.zeros((M, K))), bf(np.zeros((N, K)))
+    part = f32(np.zeros((M, 2, 2)))
+    cs = f32(np.zeros(N))
+    Cm = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    for flags, n, npseg in ((4, N, 2), (2, N, 2), (8, 200, 2), (8, N, 4)):   # the 128x128 kernel, the generic kernel, a ragged N, 4 segments
+        ck(lib, lib.cmp_gemm_ln_next(P(part), npseg, EPS, P(cs), None, None, None))
+        rc = lib.cmp_k_gemm(stream(), BF16, 0, 1, M, n, K, P(A), K, P(W), K, P(Cm), N, None, 0, None, 0, None, 0, 0, 1, 0.0, 0, 0, flags)
+        assert rc != 0 and b"LayerNorm" in lib.cmp_last_error()
+    torch.cuda.synchronize()
+    # ... and the request does not leak into the next call
+    ck(lib, lib.cmp_k_gemm(stream(), BF16, 0, 1, M, N, K, P(A), K, P(W), K, P(Cm), N, None, 0, None, 0, None, 0, 0, 1, 0.0, 0, 0, 8))
+    torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm backward from partials
+@pytest.mark.parametrize("E", [512, 768, 1024])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_layernorm_backward_from_partials_writes_the_forward_output(lib, E, p):
+    rows = 1500
+    rng = np.random.default_rng(E + int(10 * p))
+    x = bf(rng.normal(1.0, 2.0, (rows, E)))
+    dy = bf(rng.normal(0, 1.0, (rows, E)))
+    res = bf(rng.normal(0, 1.0, (rows, E)))
+    g = (1 + 0.3 * rng.normal(size=E)).astype(np.float32)
+    be = rng.normal(0, 0.2, E).astype(np.float32)
+    x64, dy64 = x.double().cpu().numpy(), dy.double().cpu().numpy()
+    part = f32(parts_of(x64))
+    ws = torch.zeros(lib.cmp_k_layernorm_bwd_ws(rows, E) // 4, device="cuda")
+    dx, yout, dmask = (torch.zeros(rows, E, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    dg, db, csum = torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    ck(lib, lib.cmp_k_layernorm_bwd_parts(stream(), P(dy), P(x), P(f32(g)), P(f32(be)), P(part), EPS, P(res), P(dx), P(yout), P(dg), P(db),
+                                          P(ws), rows, E, P(dmask), P(csum), p, 5, 2))
+    torch.cuda.synchronize()
+    g64 = g.astype(np.float64)
+    mu, var = x64.mean(-1, keepdims=True), x64.var(-1, keepdims=True)
+    rs = 1 / np.sqrt(var + EPS)
+    xh = (x64 - mu) * rs
+    gg = dy64 * g64
+    want_dx = res.double().cpu().numpy() + rs * (gg - gg.mean(-1, keepdims=True) - xh * (gg * xh).mean(-1, keepdims=True))
+    assert rel(dx.double().cpu().numpy(), want_dx) < 6e-3
+    assert rel(yout.double().cpu().numpy(), xh * g64 + be) < 6e-3
+    assert rel(dg.cpu().numpy(), (dy64 * xh).sum(0)) < 1e-4
+    assert rel(db.cpu().numpy(), dy64.sum(0)) < 1e-4
+    stored = dx.double().cpu().numpy()
+    keep = O.dropout_keep_rows(5, 2, rows, E, p) if p > 0 else np.ones((rows, E), bool)
+    want_mask = np.where(keep, stored / (1 - p), 0.0)
+    assert rel(dmask.double().cpu().numpy(), want_mask) < 5e-3          # written also with p = 0: the fused path's masked copy
+    assert rel(csum.cpu().numpy(), dmask.double().cpu().numpy().sum(0)) < 1e-4
+
+
+# --------------------------------------------------------------------------------------------- model level
+def _model(E, H, L, T, B, p, seed=3):
+    from composer_amd.transformer import Transformer
+    m = Transformer(V, E, T, L, H, attention_dropout_rate=p, residual_dropout_rate=p, dtype="bf16", seed=seed, max_batch=B, max_seq=T)
+    return m
+
+
+def _fused(m):
+    from composer_amd import _lib
+    f, n = C.c_int(-1), C.c_int64(-1)
+    _lib.check(_lib.load().cmp_model_path_info(m._h, C.byref(f), C.byref(n)))
+    return f.value, n.value
+
+
+@pytest.mark.parametrize("E,H,L,T,B,p", [(512, 8, 2, 256, 96, 0.1), (768, 12, 2, 512, 32, 0.0)])
+def test_fused_path_matches_the_unfused_path_and_the_oracle(E, H, L, T, B, p):
+    """Same weights, same batch, same dropout masks: loss and EVERY parameter gradient of the fused path against (a) the unfused
+    path of the same library (COMPOSER_LN_FUSED=0) and (b) the bf16-rounding float64 oracle on a slice of the batch small enough
+    for it (rows are independent up to the 1/(B*T) loss scale); then three train steps of each path track each other."""
+    from composer_amd import _lib
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, T, L, seed=E, stddev=0.05).items()}
+    rng = np.random.default_rng(E + L)
+    for n in params:                                                  # LayerNorm parameters away from (1, 0): the fold must carry them
+        if n.endswith("gamma"):
+            params[n] = (1 + 0.2 * rng.normal(size=params[n].shape)).astype(np.float32)
+        if n.endswith("beta"):
+            params[n] = (0.1 * rng.normal(size=params[n].shape)).astype(np.float32)
+    x, y = O.synthetic_batch(rng, V, B, T)
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["COMPOSER_LN_FUSED"] = "2" if mode == "1" else "0"          # 2: training passes take the fused path too
+        try:
+            m = _model(E, H, L, T, B, p)
+            m.set_weights(params)
+            loss, acc = m.loss_and_grads(x, y)
+            assert _fused(m)[0] == int(mode)
+            grads = {n: m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64) for n in m.parameter_names}
+            steps = [m.train_step(x, y, 1e-3)[0] for _ in range(3)]
+            if mode == "1":
+                assert _fused(m)[1] == L                               # one item table per block, built once (padding bytes in the key)
+            res[mode] = (loss, acc, grads, steps)
+            m.close()
+        finally:
+            os.environ.pop("COMPOSER_LN_FUSED", None)
+    (lf, af, gf, sf), (lu, au, gu, su) = res["1"], res["0"]
+    assert abs(lf - lu) <= 2e-3 * abs(lu), (lf, lu)
+    bad = {n: np.abs(gf[n] - gu[n]).max() / (np.abs(gu[n]).max() + 1e-12) for n in gu}
+    bad = {n: w for n, w in bad.items() if not w <= 3e-2}
+    assert not bad, bad
+    assert all(abs(a - b) <= 1e-2 * abs(b) for a, b in zip(sf, su)), (sf, su)
+    assert sf[-1] < sf[0]
+
+
+def test_fused_forward_logits_match_the_oracle_rows():
+    """Inference forward (cmp_forward_logits) on the fused path against the bf16-rounding oracle, row by row for a few rows of a batch
+    large enough to take it (rows of a batch are independent in the forward pass)."""
+    E, H, L, T, B = 512, 8, 2, 256, 96
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, T, L, seed=5, stddev=0.05).items()}
+    rng = np.random.default_rng(9)
+    for n in params:
+        if n.endswith("gamma"):
+            params[n] = (1 + 0.2 * rng.normal(size=params[n].shape)).astype(np.float32)
+        if n.endswith("beta"):
+            params[n] = (0.1 * rng.normal(size=params[n].shape)).astype(np.float32)
+    x, _ = O.synthetic_batch(rng, V, B, T)
+    m = _model(E, H, L, T, B, 0.0)
+    m.set_weights(params)
+    logits = m(x, training=False)[0]
+    assert _fused(m)[0] == 1
+    m.close()
+    orc = O.OracleTransformer(O.Config(V, E, T, L, H), params, emulate_bf16=True)
+    for b in (0, 41, 95):
+        want = np.asarray(orc.forward(x[b:b + 1])[0])
+        got = np.asarray(logits)[b:b + 1]
+        assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max(), b
