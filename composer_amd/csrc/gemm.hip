@@ -541,6 +541,13 @@ __device__ __forceinline__ void dma16(v4i32 srd, uint32_t lds_addr, int voff) {
 // delivered once they have landed (~2 us with the whole chip loading) -- the epilogue then starts after the slab it was meant
 // to overlap.  NPRE = operand chunks requested up front (16: all of them, the rest of the epilogue issues no load; 2: the rolling
 // form of the deep-pipeline kernels, which keep their stages in flight across the epilogue anyway).
+// experiment switches (tools/ab_build.py): default-policy stores for more kinds
+#ifndef XC_PLAIN_RESID
+#define XC_PLAIN_RESID 0
+#endif
+#ifndef XC_PLAIN_PLAINKIND
+#define XC_PLAIN_PLAINKIND 0
+#endif
 template <int KIND, int LNM, int NP>
 struct EpiPre {
     float b[8];                 // bias
@@ -548,13 +555,16 @@ struct EpiPre {
     bf16x8 opnd[16];            // residual / gelu' operand of every chunk
     f32x2 pt[2][NP];            // LayerNorm on the way in: partial statistics of rows lane and lane + 64 of the wave's 128
 };
-template <int KIND>
+template <int KIND, int LNM = 0>
 __device__ __forceinline__ bf16x8 epi_opnd(const Epilogue& ep, int row0, int col, int c, int rl) {
     const bf16_t* __restrict__ src = KIND == EPI_RESID ? (const bf16_t*)ep.resid : (const bf16_t*)ep.aux;
     const int lds = KIND == EPI_RESID ? ep.ldr : ep.ldaux;
     const int row = row0 + c * 8 + rl;
     // the 4E-wide pre-activation stream (0.5 GB per launch at B=128) is read non-temporally: 408 -> 380 us same-box;
     // for the E-wide residual the hint measured neutral
+    // fused block path: the residual operand of a c_proj GEMM is read for the last time -- non-temporal, so that it does not
+    // take Infinity Cache room from the rows this GEMM writes for the next one (profiles/r5_01_ln_fused.txt)
+    if (LNM != 0) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col));
     if (KIND == EPI_GELUGRAD) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col));
     return *reinterpret_cast<const bf16x8*>(src + (int64_t)row * lds + col);
 }
@@ -624,7 +634,7 @@ __device__ __forceinline__ void epi_prefetch(const Epilogue& ep, int row0, int c
     if constexpr (LOADS) {
         const int rl = lane >> 3;
 #pragma unroll
-        for (int c = 0; c < NPRE; c++) pre.opnd[c] = epi_opnd<KIND>(ep, row0, col, c, rl);
+        for (int c = 0; c < NPRE; c++) pre.opnd[c] = epi_opnd<KIND, LNM>(ep, row0, col, c, rl);
     }
 }
 template <int KIND, bool XOR_STG, int LNM = 0, int NP = 1, int NPRE = 2>
@@ -674,7 +684,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
                 }
             }
         }
-        if (LOADS && c + NPRE < 16) pre.opnd[c + NPRE] = epi_opnd<KIND>(ep, row0, col, c + NPRE, rl);
+        if (LOADS && c + NPRE < 16) pre.opnd[c + NPRE] = epi_opnd<KIND, LNM>(ep, row0, col, c + NPRE, rl);
         const int r16 = it * 8 + rl;
         f32x4 v0, v1;
         if (XOR_STG) {
@@ -737,7 +747,12 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         // Residual-stream rows of the fused block path are read next by a GEMM (the fold), not streamed by a LayerNorm kernel:
         // default-policy stores there (inference forward of C2 7.88 -> 7.67 ms same-box; non-temporal everywhere else)
 #ifndef EPI_LNOUT_NT_STORE
-        if (LNM != 0 && KIND == EPI_RESID) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
+        if ((LNM != 0 || XC_PLAIN_RESID) && KIND == EPI_RESID) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
+        else if (XC_PLAIN_PLAINKIND && KIND == EPI_PLAIN && LNM == 0) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
+        else
+#endif
+#ifdef LNX_FOLD_PLAIN
+        if (LNM != 0 && (KIND == EPI_PLAIN || (LNX_FOLD_PLAIN > 1 && KIND == EPI_GELU_AUX))) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
         else
 #endif
         __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col));
@@ -1025,7 +1040,7 @@ struct ItemPuller {
 #define H_IMG (256 * 64 * 2)
 __device__ __forceinline__ int cslow_off512(int k, int c) { return k * 512 + ((c ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1)) << 4); }
 
-template <bool KM>
+template <bool KM, int AUX = 0>
 __device__ __forceinline__ void glds_tile256(__amdgpu_buffer_rsrc_t rs, char* img, int ld_bytes, int k0, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1040,7 +1055,7 @@ __device__ __forceinline__ void glds_tile256(__amdgpu_buffer_rsrc_t rs, char* im
             const int c = (lane & 31) ^ (((k & 3) | (((k >> 3) & 1) << 2)) << 1);
             voff = (k0 + k) * ld_bytes + c * 16;
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(img + p * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(img + p * 1024), 16, voff, 0, 0, AUX);
     }
 }
 template <bool KM>
@@ -1075,6 +1090,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                                                                Epilogue ep, int ktiles_per_split, int nsplit, int tiles_n,
                                                                int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A img | B img]
+    // Cache policy of the A-operand DMA.  The two c_proj GEMMs of the fused block path read att / g for the last time and write the
+    // rows the NEXT GEMM folds a LayerNorm into: their A stream is non-temporal (aux = 2) and their output stores default-policy,
+    // so the consumer finds its A operand in the Infinity Cache instead of HBM (a fold GEMM on a cold A: +30...+100 us per launch
+    // at C2, tools/chain_bench.py; inference forward of C2 7.51 -> 7.22 ms same-box with both, profiles/r5_01_ln_fused.txt).
+#ifdef XA_NT_ALL
+    constexpr int A_AUX = 2;
+#else
+    constexpr int A_AUX = (EPI == EPI_RESID && LNM != 0) ? 2 : 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -1118,7 +1142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
     __amdgpu_buffer_rsrc_t ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
     if (kt0 < kt1) {
-        glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
+        glds_tile256<A_KM, A_AUX>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
         glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
     }
     bool run = true;      // false: this workgroup's first item was taken by another one before it got to run
@@ -1145,12 +1169,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             // 3 = no DMA inside the k-loop, 4 = neither reads nor DMA (MFMA + barrier only), 5 = as 1 with TWO stage loads per step
             if (kt + 1 < kt1 && GEMM_DIAG != 3 && GEMM_DIAG != 4) {
                 char* na = smem + (st ^ 1) * 2 * H_IMG;
-                glds_tile256<A_KM>(ra, na, lda * 2, (kt + 1) * G_BK, wave, lane);
+                glds_tile256<A_KM, A_AUX>(ra, na, lda * 2, (kt + 1) * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, (kt + 1) * G_BK, wave, lane);
 #if GEMM_DIAG == 5
                 // bandwidth probe: a second, different slab per step into the same buffer -> 128 KiB in flight per CU
                 const int k2 = (kt + 1 + (kt1 - kt0) / 2) % (kt1 - kt0) + kt0;
-                glds_tile256<A_KM>(ra, na, lda * 2, k2 * G_BK, wave, lane);
+                glds_tile256<A_KM, A_AUX>(ra, na, lda * 2, k2 * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, k2 * G_BK, wave, lane);
 #endif
             }
@@ -1256,7 +1280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
             if (kt0 < kt1) {
-                glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
+                glds_tile256<A_KM, A_AUX>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
             }
         }
@@ -1350,7 +1374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
             if (kt0 < kt1) {
-                glds_tile256<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
+                glds_tile256<A_KM, A_AUX>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
             }
         }
@@ -2196,6 +2220,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
     ep.sched = ep.sched_clear = nullptr;
     ep.ln = ex.ln;
     ep.rev = ex.rev ? 1 : 0;
+
     const int lnm = (ex.ln.in_part ? 1 : 0) | (ex.ln.out_part ? 2 : 0);
     bool ln_done = lnm == 0;         // a launch that asks for a LayerNorm epilogue must reach a kernel that has one
     float* colsum_out = ex.colsum;
