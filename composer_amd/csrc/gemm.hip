@@ -598,11 +598,13 @@ __device__ __forceinline__ void epi_prefetch(const Epilogue& ep, int row0, int c
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int s = 0; s < NP; s++) pre.pt[h][s] = *reinterpret_cast<const f32x2*>(fold_img + ((h * 64 + lane) * NP + s) * 8);
-        const float* vb = reinterpret_cast<const float*>(fold_img + NP * 1024) + (lane & 7) * 8;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(vb), b1 = *reinterpret_cast<const f32x4*>(vb + 4);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(vb + 64), a1 = *reinterpret_cast<const f32x4*>(vb + 68);
+        if constexpr (KIND != EPI_GELU_AUX) {          // (the GELU kind re-reads them per chunk, see epi_tile)
+            const float* vb = reinterpret_cast<const float*>(fold_img + NP * 1024) + (lane & 7) * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(vb), b1 = *reinterpret_cast<const f32x4*>(vb + 4);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(vb + 64), a1 = *reinterpret_cast<const f32x4*>(vb + 68);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { pre.b[j] = b0[j]; pre.b[4 + j] = b1[j]; pre.lnA[j] = a0[j]; pre.lnA[4 + j] = a1[j]; }
+            for (int j = 0; j < 4; j++) { pre.b[j] = b0[j]; pre.b[4 + j] = b1[j]; pre.lnA[j] = a0[j]; pre.lnA[4 + j] = a1[j]; }
+        }
         return;
     }
     if constexpr (LN_IN) {
@@ -640,9 +642,10 @@ __device__ __forceinline__ void epi_prefetch(const Epilogue& ep, int row0, int c
 template <int KIND, bool XOR_STG, int LNM = 0, int NP = 1, int NPRE = 2>
 __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict__ C, int ldc, int row0, int col, float* stg,
                                          int lane, const f32x4 (&acc)[8][4], EpiPre<KIND, LNM, NP>& pre, f32x2* lstat = nullptr,
-                                         f32x2* lrow = nullptr) {
+                                         f32x2* lrow = nullptr, const char* fold_vec = nullptr) {
     constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
     constexpr bool LN_IN = (LNM & 1) != 0, LN_OUT = (LNM & 2) != 0;
+    constexpr bool FOLD_VEC_LDS = LN_IN && KIND == EPI_GELU_AUX;
     const int rl = lane >> 3;
     float cs[8];
 #pragma unroll
@@ -706,8 +709,21 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         if (LN_IN && KIND != EPI_RESID) {
             // rstd * acc - rstd*mean * colsum(gamma o W) + (beta.W + b)
             const float mrs = ln_mu * ln_rs;
+            if constexpr (FOLD_VEC_LDS) {
+                // bias' and the column sums are re-read from the wave's DMA image for every chunk (sixteen registers less across the
+                // epilogue: with them held, the GELU fold kind at 3 segments went over 256 registers and hipcc put a full
+                // `s_waitcnt vmcnt(0)` at the top of its k-step -- c_fc of C4 372 us against 318 unfused)
+                const volatile f32x4* vb = reinterpret_cast<const volatile f32x4*>(fold_vec) + (lane & 7) * 2;
+                const f32x4 b0 = vb[0], b1 = vb[1], a0 = vb[16], a1 = vb[17];
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = fmaf(ln_rs, v[j], fmaf(-mrs, pre.lnA[j], pre.b[j]));
+                for (int j = 0; j < 4; j++) {
+                    v[j] = fmaf(ln_rs, v[j], fmaf(-mrs, a0[j], b0[j]));
+                    v[4 + j] = fmaf(ln_rs, v[4 + j], fmaf(-mrs, a1[j], b1[j]));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = fmaf(ln_rs, v[j], fmaf(-mrs, pre.lnA[j], pre.b[j]));
+            }
         } else if (KIND != EPI_GELUGRAD) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] += pre.b[j];
@@ -1301,7 +1317,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                 epi_tile<EPI, false, LNM, NP, 2>(ep, (bf16_t*)C, ldc, cm0 + wm * 128, col, stg, lane, acc, pre,
                                                   reinterpret_cast<f32x2*>(smem + LN_STAT_OFF) + wn * 256 + wm * 128,
                                                   FOLD ? reinterpret_cast<f32x2*>(smem + fold_off)
-                                                       : reinterpret_cast<f32x2*>(smem + LN_STAT_OFF + 8192) + wave * 128);
+                                                       : reinterpret_cast<f32x2*>(smem + LN_STAT_OFF + 8192) + wave * 128,
+                                                  smem + fold_off + NP * 1024);
             } else {
             const int rbase = cm0 + wm * 128 + (lane >> 3);
             float bias8[8];
