@@ -767,10 +767,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         else if (XC_PLAIN_PLAINKIND && KIND == EPI_PLAIN && LNM == 0) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
         else
 #endif
-#ifdef LNX_FOLD_PLAIN
-        if (LNM != 0 && (KIND == EPI_PLAIN || (LNX_FOLD_PLAIN > 1 && KIND == EPI_GELU_AUX))) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
-        else
-#endif
+
         __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col));
         if (ep.colsum) {
 #pragma unroll

@@ -126,6 +126,8 @@ struct cmp_model {
     const float* fwd_amask = nullptr;          // ... and its additive attention mask term, float [B, past + T]
     float* const* fwd_probs_out = nullptr;     // ... and, when asked for, L host tensors [B, H, T, past + T] for the attention weights
     float* fwd_probs_dev = nullptr;            //     (one layer's worth of device staging)
+    void* io_buf[3] = {nullptr, nullptr, nullptr};     // device staging of the inspection entry points (model.hip: io_scratch)
+    size_t io_buf_bytes[3] = {0, 0, 0};
     std::vector<LayerAct> act;
     void *hf = nullptr, *dlogits = nullptr;
     float* logits_pack = nullptr;      // [tokens, V] contiguous copy of the logits for cmp_forward's host transfer (allocated on first use)
@@ -168,6 +170,8 @@ struct cmp_model {
     double dp_exposed_ms = 0.0;
     int64_t dp_bytes_step = 0;         // bytes handed to ncclAllReduce by the last step (gradients + the 3-float metrics message)
     int dp_msgs_step = 0;              // all-reduce calls of the last step
+    int dp_buckets_updated = 0;        // buckets of the step being enqueued whose Adam update is already on the communication stream
+    bool poisoned = false;             // a data-parallel step failed after some of them: parameters partially stepped (train steps refuse)
     DecodeState* dec = nullptr;
     int gemm_role = -1;                // profiler class of the GEMMs being enqueued (0 while the forward pass is)
 

@@ -369,7 +369,7 @@ extern "C" int cmp_model_destroy(cmp_model* m) {
     hipStreamSynchronize(m->ctx->comm_stream);
     if (m->ctx->copy_stream) hipStreamSynchronize(m->ctx->copy_stream);
     if (m->dec) decode_state_free(m->dec);
-    for (void* p : m->allocs) hipFree(p);
+    for (void* p : m->allocs) if (p) hipFree(p);
     for (auto& wg : m->wgrad_groups) wgrad_group_free(&wg);
     if (m->metrics_host) hipHostFree(m->metrics_host);
     if (m->stage_metrics) hipHostFree(m->stage_metrics);
@@ -478,7 +478,7 @@ extern "C" int cmp_param_set(cmp_model* m, const char* name, int kind, const flo
         HIP_CHECK(hipMemcpyAsync(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice, m->ctx->stream));
         HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     }
-    if (kind == 0) m->param_version += 1;
+    if (kind == 0) { m->param_version += 1; m->poisoned = false; }      // (a checkpoint reload goes through here for every tensor)
     if (kind == 0 && m->S) {
         int64_t n8 = (p.store + 7) / 8 * 8;
         CHECK_RC(launch_cast_bf16(m->ctx->stream, m->P + p.offset, m->S + p.offset, n8));
@@ -862,8 +862,8 @@ static int adam_range(cmp_model* m, hipStream_t s, int64_t begin, int64_t end, f
 // end-of-step wait instead of every bucket's update.
 // Runs whenever a communicator exists, also with ONE rank (RCCL then copies in place): the 1-GPU tests and a 1-rank
 // launched bench execute exactly the event / side-stream / ncclAllReduce sequence of the 8-GPU job.
-// lr < 0: gradients only (no update).
-static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end, float lr) {
+// update == false: gradients only (cmp_loss_and_grads).
+static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end, float lr, bool update) {
     cmp_ctx* c = m->ctx;
     if (!c->comm) return CMP_OK;
     HIP_CHECK(hipEventRecord(m->bucket_ev[ev], c->stream));
@@ -871,12 +871,15 @@ static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end, float 
     NCCL_CHECK(ncclAllReduce(m->G + begin, m->G + begin, (size_t)(end - begin), ncclFloat, ncclSum, c->comm, c->comm_stream));
     m->dp_bytes_step += (end - begin) * 4;
     m->dp_msgs_step += 1;
-    if (lr >= 0.f) CHECK_RC(adam_range(m, c->comm_stream, begin, end, lr, m->iterations + 1, 1.0f / (float)c->nranks));
+    if (update) {
+        CHECK_RC(adam_range(m, c->comm_stream, begin, end, lr, m->iterations + 1, 1.0f / (float)c->nranks));
+        m->dp_buckets_updated += 1;
+    }
     return CMP_OK;
 }
 
 // reverse mode of forward() (tf.GradientTape, transformer.py:916-920); formulas in SURVEY appendix A
-static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t step, bool allreduce, float lr = -1.f) {
+static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t step, bool allreduce, float lr = 0.f, bool update = false) {
     Range range_("composer.backward");
     hipStream_t s = m->ctx->stream;
     const int E = m->E, Ea = m->Ea, M = B * T, dt = m->dtype, V = m->V;
@@ -913,7 +916,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     const bool fused = m->fused_last;
     void* const dmk[2] = {m->dmask, m->dmask3};
     int cur = 0;
-    if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total, lr));
+    if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total, lr, update));
     // The four Conv1D weight gradients of a block contract over the same M tokens: with LayerNorm, bf16 and the atomic
     // (non-deterministic) split-K form they go out as ONE grouped launch behind the block's attention backward (gemm.hip:
     // gemm_wgrad_group_kernel) -- a quarter of the f32-atomic traffic of four split-K launches, equal k-steps per workgroup.
@@ -1019,12 +1022,12 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * Ea, m->dqkv, 3 * Ea, m->w(o.attn_w), 3 * Ea, m->dx, E, nullptr, 0, nullptr, 0, m->dr, E,
                           0, 1, 0.f, 0));
         }
-        if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end, lr));
+        if (allreduce) CHECK_RC(bucket_ready(m, i, o.begin, o.end, lr, update));
     }
     CHECK_RC(embed_bwd_run(s, x_dev, m->dx, m->G + m->off_wte, m->G + m->off_wpe, B, T, E, 0, dt, pr, m->drop_seed(),
                            drop_stream(step, 0, 0), m->slab ? V : 0, (float*)m->slab, (size_t)m->slab_bytes, V, m->embed_ws,
                            m->embed_ws_words));
-    if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin, lr));
+    if (allreduce) CHECK_RC(bucket_ready(m, m->L + 1, 0, m->lo[0].begin, lr, update));
     return CMP_OK;
 }
 
@@ -1136,14 +1139,29 @@ __global__ void sanitize_ids_kernel(const int32_t* __restrict__ x, const int32_t
 
 // the step itself on ids already in HBM and already known to be in range
 static int train_step_enqueue(cmp_model* m, const int32_t* x_dev, const int32_t* y_dev, int B, int T, float lr) {
+    // everything that can be checked is checked before anything is enqueued: in a data-parallel job the peers are already in the
+    // metrics all-reduce by the time the backward pass starts
+    CMP_REQUIRE(lr >= 0.f && lr == lr, "train step: learning rate %g is not a non-negative number", (double)lr);
+    CMP_REQUIRE(!m->poisoned, "train step: an earlier data-parallel step failed after some gradient buckets had been all-reduced and "
+                "applied (parameters are partially stepped and may differ between replicas): reload a checkpoint on every rank");
     const int64_t step = m->iterations;
     CHECK_RC(model_forward(m, x_dev, B, T, true, step));
     CHECK_RC(loss(m, y_dev, B * T, true));
     CHECK_RC(dp_metrics_begin(m));
-    CMP_REQUIRE(lr >= 0.f, "train step: learning rate %g is negative", (double)lr);
-    CHECK_RC(backward(m, x_dev, B, T, step, true, lr));
-    CHECK_RC(adam(m, lr));
-    return CMP_OK;
+    m->dp_buckets_updated = 0;
+    int rc = backward(m, x_dev, B, T, step, true, lr, true);
+    if (rc == CMP_OK) rc = adam(m, lr);
+    if (rc != CMP_OK && m->ctx->comm) {
+        // Buckets already handed to the communication stream keep running (all-reduce + Adam): the compute stream must not touch
+        // G / P before they are done (the next step's memset of G would race them), and a model whose buckets were partly
+        // updated is no longer the model the caller thinks it has.  The failing call's message is kept.
+        cmp_ctx* c = m->ctx;
+        if (hipEventRecord(m->comm_done, c->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, m->comm_done, 0);
+        else (void)hipStreamSynchronize(c->comm_stream);
+        (void)hipGetLastError();
+        if (m->dp_buckets_updated > 0) m->poisoned = true;
+    }
+    return rc;
 }
 
 extern "C" int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, float lr) {
@@ -1305,6 +1323,26 @@ __global__ void present_gather_kernel(const T_* __restrict__ qkv, float* __restr
         out[i] = to_f32<T_>(qkv[((int64_t)b * T + t) * 3 * E + (1 + kv) * E + h * Dk + d]);
     }
 }
+// Device staging of the inspection entry points (presents, hidden states, the optional inputs of cmp_forward_ex): kept in the
+// model and grown on demand -- a hipMalloc / hipFree pair per call is two device-wide synchronisations (hipFree waits for every
+// stream of the device: it stalled other models sharing the device, tools/thread_probe.py).  slot: 0 / 1 / 2 independent buffers.
+static int io_scratch(cmp_model* m, int slot, size_t bytes, void** out) {
+    if (m->io_buf_bytes[slot] < bytes) {
+        if (m->io_buf[slot]) {
+            HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+            for (auto& p : m->allocs) if (p == m->io_buf[slot]) { p = nullptr; break; }
+            (void)hipFree(m->io_buf[slot]);
+            m->io_buf[slot] = nullptr; m->io_buf_bytes[slot] = 0;
+        }
+        void* q = nullptr;
+        const size_t want = std::max(bytes, (size_t)1 << 16);
+        HIP_CHECK(hipMalloc(&q, want));
+        m->allocs.push_back(q);
+        m->io_buf[slot] = q; m->io_buf_bytes[slot] = want;
+    }
+    *out = m->io_buf[slot];
+    return CMP_OK;
+}
 extern "C" int cmp_forward_generation(cmp_model* m, int64_t* gen) {
     CMP_REQUIRE(m && gen, "forward_generation: null argument");
     *gen = m->fwd_gen;
@@ -1326,14 +1364,13 @@ extern "C" int cmp_present_get(cmp_model* m, int layer, int B, int T, float* hos
     HIP_CHECK(hipSetDevice(m->ctx->device));
     const int64_t n = (int64_t)2 * B * m->H * T * m->Dl;
     float* tmp = nullptr;
-    HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
+    CHECK_RC(io_scratch(m, 0, (size_t)n * 4, (void**)&tmp));
     const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
     if (m->dtype == CMP_BF16) present_gather_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)m->act[layer].qkv, tmp, B, T, m->H, m->Dl, m->D);
     else present_gather_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)m->act[layer].qkv, tmp, B, T, m->H, m->Dl, m->D);
-    hipError_t e = hipMemcpyAsync(host_out, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, m->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(tmp);
-    HIP_CHECK(e);
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemcpyAsync(host_out, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     return CMP_OK;
 }
 
@@ -1356,14 +1393,13 @@ extern "C" int cmp_hidden_get_at(cmp_model* m, int index, int B, int T, int64_t 
     const int64_t n = (int64_t)B * T * m->E;
     const void* src = index < m->L ? m->xs[index] : m->hf;
     float* tmp = nullptr;
-    HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
+    CHECK_RC(io_scratch(m, 0, (size_t)n * 4, (void**)&tmp));
     const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
     if (m->dtype == CMP_BF16) hidden_unpack_kernel<bf16_t><<<grid, 256, 0, m->ctx->stream>>>((const bf16_t*)src, tmp, n);
     else hidden_unpack_kernel<float><<<grid, 256, 0, m->ctx->stream>>>((const float*)src, tmp, n);
-    hipError_t e = hipMemcpyAsync(host_out, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, m->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(tmp);
-    HIP_CHECK(e);
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemcpyAsync(host_out, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     return CMP_OK;
 }
 
@@ -1422,21 +1458,19 @@ extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int 
     CHECK_RC(upload_xy(m, x, nullptr, B, T, past_len));
     hipStream_t s = m->ctx->stream;
     // the optional id tensors ride in one device buffer that lives for this call
-    struct IdBuf {
+    struct IdBuf {          // (the buffers themselves live in the model: io_scratch)
         cmp_model* m;
         int32_t* dev = nullptr;
         ~IdBuf() {
             m->fwd_pos_ids = m->fwd_type_ids = nullptr;
             m->fwd_amask = nullptr;
             m->fwd_probs_out = nullptr;
-            if (m->fwd_probs_dev) (void)hipFree(m->fwd_probs_dev);
             m->fwd_probs_dev = nullptr;
-            if (dev) (void)hipFree(dev);
         }
     } idbuf{m};
     if (attention_weights_out) {
         for (int i = 0; i < m->L; i++) CMP_REQUIRE(attention_weights_out[i], "forward: attention_weights_out[%d] is null", i);
-        HIP_CHECK(hipMalloc((void**)&m->fwd_probs_dev, (size_t)B * m->H * T * (past_len + T) * 4));
+        CHECK_RC(io_scratch(m, 1, (size_t)B * m->H * T * (past_len + T) * 4, (void**)&m->fwd_probs_dev));
         m->fwd_probs_out = attention_weights_out;
     }
     if (position_ids || token_type_ids || attention_mask) {
@@ -1446,7 +1480,7 @@ extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int 
                 CMP_REQUIRE(position_ids[i] >= 0 && position_ids[i] < m->W, "forward: position id %d at %lld outside the wpe table [0, %d)",
                             position_ids[i], (long long)i, m->W);
         if (token_type_ids) CHECK_RC(check_host_ids(m, token_type_ids, n, "token type ids"));
-        HIP_CHECK(hipMalloc((void**)&idbuf.dev, (size_t)(2 * n + 2 * nk) * 4));
+        CHECK_RC(io_scratch(m, 2, (size_t)(2 * n + 2 * nk) * 4, (void**)&idbuf.dev));
         if (position_ids) {
             HIP_CHECK(hipMemcpyAsync(idbuf.dev, position_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
             m->fwd_pos_ids = idbuf.dev;
@@ -1468,7 +1502,7 @@ extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int 
         const int64_t n = (int64_t)2 * B * m->H * past_len * m->Dl;         // the host tensors: [2, B, H, past_len, E / H]
         const int64_t ns = (int64_t)2 * B * m->H * past_len * m->D;        // K/V elements written (zero-padded heads included)
         float* tmp = nullptr;
-        HIP_CHECK(hipMalloc(&tmp, (size_t)n * 4));
+        CHECK_RC(io_scratch(m, 0, (size_t)n * 4, (void**)&tmp));
         int rc = CMP_OK;
         for (int i = 0; i < m->L && rc == CMP_OK; i++) {
             if (!past[i]) { cmp_set_error("forward: past[%d] is null", i); rc = CMP_ERR_INVALID; break; }
@@ -1480,7 +1514,6 @@ extern "C" int cmp_forward_ex(cmp_model* m, const int32_t* x, int B, int T, int 
             e = hipStreamSynchronize(s);          // tmp is reused by the next layer's upload
             if (e != hipSuccess) { cmp_set_error("forward: past scatter: %s", hipGetErrorString(e)); rc = CMP_ERR_HIP; }
         }
-        (void)hipFree(tmp);
         CHECK_RC(rc);
     }
     CHECK_RC(model_forward(m, m->x_dev, B, T, training != 0, m->iterations, past_len));

@@ -297,7 +297,12 @@ class Transformer:
                 raise IndexError('position id outside the wpe table (window_size %d, transformer.py:675-679,786)' % self.window_size)
         amask = None
         if attention_mask is not None:                                           # :774-779, 356-358: [B, past + new keys], 1 = attend
-            amask = np.ascontiguousarray(np.asarray(attention_mask).astype(np.int32))
+            raw = np.asarray(attention_mask)
+            # the reference casts the mask to float32 and adds (1 - mask) * -1e4 (:774-779): a fractional entry is a soft mask there.
+            # The C ABI carries 0 / 1 integers, so anything else is refused rather than truncated to "masked".
+            if raw.size and not np.all((raw == 0) | (raw == 1)):
+                raise ValueError('attention_mask entries must be 0 or 1 (soft masks are not supported by the HIP path)')
+            amask = np.ascontiguousarray(raw.astype(np.int32))
             if amask.shape != (B, past_len + T):
                 raise ValueError('attention_mask must be [batch, past_len + sequence] = %s; got %s' % ((B, past_len + T), amask.shape))
         attentions, att_ptrs = None, None

@@ -404,6 +404,13 @@ def test_position_ids_and_token_type_ids_match_the_oracle(dtype, tol):
         m(x, token_type_ids=np.full((B, T), V, np.int32))
     with pytest.raises(NotImplementedError):
         m(x, input_embeddings=np.zeros((B, T, E), np.float32))
+    # a fractional attention mask is a SOFT mask in the reference (float32 cast, transformer.py:774-779); the HIP path carries
+    # 0 / 1 and refuses anything else instead of truncating it to "masked"
+    soft = np.ones((B, T), np.float32)
+    soft[0, 1] = 0.5
+    with pytest.raises(ValueError):
+        m(x, attention_mask=soft)
+    m(x, attention_mask=np.ones((B, T), np.float32))                            # float 0 / 1 masks are fine
     m.close()
 
 
