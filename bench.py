@@ -66,15 +66,31 @@ def pmc_traffic(kernel_class, tokens, cfg_name):
     (profiles/hbm_traffic.json, made by tools/profile_round4.sh + tools/make_traffic_json.py: `rocprofv3 --pmc FETCH_SIZE` and
     `--pmc WRITE_SIZE` in separate runs of `python3 bench.py --no-extras --no-cpu-baseline --no-decode`, the gfx950 FETCH_SIZE
     correction applied).  Counters cannot be read from inside this process; None when the file does not cover the run."""
+    return pmc_traffic_note(kernel_class, tokens, cfg_name)[0]
+
+
+def pmc_traffic_note(kernel_class, tokens, cfg_name):
+    """(bytes per launch or None, why).  A run of the file counts only while the library it was measured on (its `build_key`, written by
+    tools/make_traffic_json.py) is the library loaded now: a kernel change makes the committed counters stale, and stale counters
+    are reported as None, never as current."""
     try:
         doc = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     except Exception:
-        return None
+        return None, "profiles/hbm_traffic.json is missing or unreadable"
     run = doc.get("runs", {}).get("%s_tokens%d" % (cfg_name, tokens))
     if not run:
-        return None
+        return None, "profiles/hbm_traffic.json has no PMC run for %s at %d tokens" % (cfg_name, tokens)
+    from composer_amd import _lib
+    key = _lib.load().cmp_build_key().decode()
+    if run.get("build_key") != key:
+        return None, ("profiles/hbm_traffic.json was measured on library build %s..., the library loaded is %s...: stale counters are not "
+                      "printed (re-run tools/profile_round5.sh)" % (str(run.get("build_key"))[:12], key[:12]))
     ent = run.get("classes", {}).get(str(kernel_class))
-    return ent.get("traffic_bytes_per_launch") if ent else None
+    if not ent:
+        return None, "class %d not in the PMC run" % kernel_class
+    return ent.get("traffic_bytes_per_launch"), ("HBM-side bytes per launch of this class inside the train step (mean over its launches): "
+                                                  "rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes over bench.py itself on this "
+                                                  "library build, profiles/hbm_traffic.json")
 
 
 def class_table(lib, step, tokens, cfg_name, reps=3):
@@ -96,6 +112,7 @@ def class_table(lib, step, tokens, cfg_name, reps=3):
                "avg_us": 1e3 * cms.value / cn.value, "ms_per_step": cms.value / reps,
                "achieved": rate / (1e12 if bound == "mfma" else 1e9), "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                "frac": rate / peak, "algorithmic_bytes": cb.value / cn.value, "traffic": pmc_traffic(cls, tokens, cfg_name)}
+        # (None when profiles/hbm_traffic.json was measured on another build of the library: pmc_traffic_note)
         if row["traffic"]:
             row["traffic_over_algorithmic"] = row["traffic"] / row["algorithmic_bytes"]
             row["hbm_gbs"] = row["traffic"] / (row["avg_us"] * 1e-6) / 1e9
@@ -125,13 +142,32 @@ def forward_bench(device):
             t0 = time.perf_counter()
             m.evaluate(ds)
             ts.append(time.perf_counter() - t0)
+        # the decoder-block stack alone (HIP events around the L blocks inside the same call, timing class 9): embedding, ln_f,
+        # tied logits, loss, metrics and the host side of the call left out -- the span north_star's "attention+FFN forward" names
+        from composer_amd import _lib
+        lib = _lib.load()
+        bts = []
+        for _ in range(10):                                    # per call, median (like `ms` above)
+            lib.cmp_prof_begin(9)
+            m.evaluate(ds)
+            bms, bn, bw, bb = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            lib.cmp_prof_end2(C.byref(bms), C.byref(bn), C.byref(bw), C.byref(bb))
+            if bn.value == 1:
+                bts.append(bms.value)
+        fused, _n = C.c_int(-1), C.c_int64(0)
+        lib.cmp_model_path_info(m._h, C.byref(fused), C.byref(_n))
         m.close()
         dt = float(np.median(ts))
         blocks = L * (24 * E * E + 2 * E * T)
         tf = B * T * (blocks + 2 * E * V) / dt / 1e12
         out[name] = {"workload": "%s inference forward, seq=%d, B=%d, bf16" % (cf["label"], T, B), "ms": 1e3 * dt,
                      "tokens_per_s": B * T / dt, "tflops": tf, "frac": tf / PEAK_BF16_TFLOPS,
-                     "frac_attn_ffn": B * T * blocks / dt / 1e12 / PEAK_BF16_TFLOPS}
+                     "frac_attn_ffn": B * T * blocks / dt / 1e12 / PEAK_BF16_TFLOPS,
+                     "layernorm_fused_block_path": bool(fused.value == 1)}
+        if bts:
+            bdt = float(np.median(bts)) * 1e-3
+            out[name]["blocks_only_ms"] = 1e3 * bdt
+            out[name]["frac_attn_ffn_blocks_only"] = B * T * blocks / bdt / 1e12 / PEAK_BF16_TFLOPS
     return out
 
 
@@ -294,6 +330,68 @@ def side_config(name, Bq, device, dropout, steps=10, warmup=3, classes=False):
     return out
 
 
+def default_config_bench(device, steps=60, warmup=10):
+    """The reference's DEFAULT workload (composer/default_config.yml:32-48, what `composer train` runs with no -c): E=256, 16 heads
+    of 16, 8 blocks, window 1024, batch_size 1, dropout 0.1 -- 1 024 tokens per step, every kernel latency-bound.  Device-pointer steps
+    back to back; `launches` = kernel launches one step enqueues (cmp_train_step_launches: counted on a dropped stream capture)."""
+    import torch
+    from composer_amd.transformer import Transformer
+    E, H, L, T, B = 256, 16, 8, 1024, 1
+    m = Transformer(V, E, T, L, H, attention_dropout_rate=0.1, residual_dropout_rate=0.1, dtype="bf16", seed=0, max_batch=B, max_seq=T,
+                    device=device)
+    m.initialize_parameters(0)
+    rng = np.random.default_rng(7)
+    seq = rng.integers(0, V, size=(B, T + 1), dtype=np.int32)
+    dev = torch.device("cuda", device)
+    x = torch.from_numpy(np.ascontiguousarray(seq[:, :-1])).to(dev)
+    y = torch.from_numpy(np.ascontiguousarray(seq[:, 1:])).to(dev)
+    for _ in range(warmup):
+        m.train_step_device(x.data_ptr(), y.data_ptr(), B, T, LR)
+    m.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step_device(x.data_ptr(), y.data_ptr(), B, T, LR)
+    m.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss, _ = m.last_metrics()
+    from composer_amd import _lib
+    nk, no = C.c_int(0), C.c_int(0)
+    rc = _lib.load().cmp_train_step_launches(m._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), B, T, C.byref(nk), C.byref(no))
+    m.close()
+    return {"workload": "default_config.yml Transformer (8L/16H/d256), seq=1024, B=1, dropout 0.10, bf16", "steps": steps,
+            "ms_per_step": 1e3 * dt, "tokens_per_s": B * T / dt, "launches": nk.value if rc == 0 else None,
+            "other_graph_nodes": no.value if rc == 0 else None, "final_loss": loss,
+            "model_mfma_frac": B * T / dt * flops_per_token_train(E, L, T) / 1e12 / PEAK_BF16_TFLOPS}
+
+
+def dp1_child(args):
+    """The product's data-parallel path on this box: a FRESH child process runs this file under torch.distributed.run with ONE rank
+    (RCCL communicator, per-block buckets on the priority side stream, Adam per bucket behind its all-reduce) and its `comm` object and
+    step time come back -- so the driver-timed N=1 line also says what the gradient exchange costs when nothing can overlap badly.
+    A child, never a re-exec: this process has initialised the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-extras",
+           "--no-cpu-baseline", "--no-decode", "--config", args.config, "--dropout", str(args.dropout)] + \
+          (["--batch", str(args.batch)] if args.batch else [])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": "child exited %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:])}
+        doc = json.loads(line[-1])
+        return {"ms_per_step": doc["ms_per_step"], "value": doc["value"], "steps": doc["steps"], "comm": doc.get("comm"),
+                "note": "bench.py under torch.distributed.run with one rank, own process: the RCCL path of the 8-GPU job"}
+    except Exception as e:                                   # the headline line must not depend on the child
+        return {"error": repr(e)[:400]}
+
+
 def self_launch(args):
     """--gpus N>1 without a launcher: run N ranks of this file under torch.distributed.run as a CHILD process (this parent
     has not touched the GPU), forward their stdout/stderr, return the launcher's exit status."""
@@ -421,12 +519,9 @@ def main():
         if n_launch.value > 0 and ms.value > 0:
             if bound == "mfma":
                 achieved = work.value / (ms.value * 1e-3) / 1e12
+                tr, why = pmc_traffic_note(args.roofline_kernel, Bq * T, args.config)
                 roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args.roofline_kernel, Bq * T, args.config)}
-                if roof["traffic"] is not None:
-                    roof["traffic_note"] = ("HBM-side bytes per launch of this class inside the train step (mean over its launches): "
-                                            "rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes over bench.py itself, "
-                                            "profiles/hbm_traffic.json")
+                        "frac": achieved / PEAK_BF16_TFLOPS, "traffic": tr, "traffic_note": why}
             else:
                 achieved = work.value / (ms.value * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -472,6 +567,12 @@ def main():
             if args.config != "c4":
                 out["c4"] = side_config("c4", CONFIGS["c4"]["B"], local_rank, args.dropout)
             out["forward"] = forward_bench(local_rank)
+            out["default_cfg"] = default_config_bench(local_rank)
+            if not under_launcher:
+                d1 = dp1_child(args)
+                if "ms_per_step" in d1:
+                    d1["vs_plain_step"] = d1["ms_per_step"] / out["ms_per_step"]
+                out["dp1"] = d1
         if world == 1 and not args.no_decode:
             out["decode"] = decode_bench(local_rank)
         print(json.dumps(out), flush=True)

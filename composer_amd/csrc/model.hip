@@ -767,6 +767,9 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
     // forward 7.22 -> 7.18 ms; COMPOSER_GEMM_ALT=0: all forwards)
     static const int alt_mode = [] { const char* e = getenv("COMPOSER_GEMM_ALT"); return e ? atoi(e) : 1; }();
     const int RV[4] = {alt_mode == 2 ? GEMM_REV : 0, alt_mode == 1 ? GEMM_REV : 0, alt_mode == 2 ? GEMM_REV : 0, alt_mode == 1 ? GEMM_REV : 0};
+    // timing class 9: the decoder-block stack of this pass as one span (bench.py `forward.*.blocks_only_ms`: the attention + FFN
+    // forward north_star prices, without embedding, ln_f, logits, loss and the host side of the call)
+    PROF_START(9, s);
     for (int i = 0; fused && i < m->L; i++) {
         // transformer.py:574-597 with both LayerNorms inside the GEMM epilogues (common.h: LnEpi)
         const LayerOff& o = m->lo[i];
@@ -822,6 +825,7 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         CHECK_RC(gemm(m, 0, wt, M, E, 4 * E, a.g, 4 * E, W(o.pr_w), wt ? 4 * E : E, m->xs[i + 1], E, m->P + o.pr_b, 0, nullptr, 0, a.r, E,
                       0, 1, pr, drop_stream(step, i, 3)));                         // x = r + dropout(mlp)   :594
     }
+    PROF_STOP(9, s, (double)M * m->L * (24.0 * E * E + 2.0 * E * Tt), 0.0);        // (causal attention on the unmasked half)
     CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[m->L], m->P + m->off_lnf_g, m->P + m->off_lnf_b, m->hf, m->lnf_mean, m->lnf_rstd, M,
                                  E, m->cfg.ln_eps, dt));                           // :811 (always applied)
     CHECK_RC(gemm(m, 0, 1, M, m->V, E, m->hf, E, m->w(m->off_wte), E, m->logits, m->ldz, nullptr, 0, nullptr, 0, nullptr, 0, 1,
@@ -1175,6 +1179,40 @@ extern "C" int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y
     KERNEL_CHECK();
     CHECK_RC(train_step_enqueue(m, m->x_dev, m->y_dev, B, T, lr));
     CHECK_RC(fetch_metrics(m));
+    return CMP_OK;
+}
+
+// Diagnostic: how many launches ONE train step of this shape enqueues.  The step is stream-captured (nothing executes), the nodes of
+// the captured graph are counted by type, the graph is dropped and the host-side state the enqueue touched is put back.  Not
+// available once a communicator exists (RCCL calls inside a capture).
+extern "C" int cmp_train_step_launches(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others) {
+    CMP_REQUIRE(m && x_dev && y_dev && kernels, "train_step_launches: null argument");
+    CMP_REQUIRE(!m->ctx->comm, "train_step_launches: not available with a communicator");
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    CHECK_RC(ensure_workspace(m, B, T));
+    hipStream_t s = m->ctx->stream;
+    HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t it = m->iterations, pv = m->param_version, gen = m->fwd_gen, stv = m->st_version;
+    const int sts = m->st_state;
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = train_step_enqueue(m, (const int32_t*)x_dev, (const int32_t*)y_dev, B, T, 0.f);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    m->iterations = it; m->param_version = pv; m->fwd_gen = gen; m->st_version = stv; m->st_state = sts;
+    if (rc != CMP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    HIP_CHECK(e);
+    size_t n = 0;
+    HIP_CHECK(hipGraphGetNodes(g, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) HIP_CHECK(hipGraphGetNodes(g, nodes.data(), &n));
+    int nk = 0, no = 0;
+    for (size_t i = 0; i < n; i++) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nodes[i], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel) nk++; else no++;
+    }
+    (void)hipGraphDestroy(g);
+    *kernels = nk;
+    if (others) *others = no;
     return CMP_OK;
 }
 

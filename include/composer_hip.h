@@ -130,6 +130,9 @@ int cmp_train_step(cmp_model* m, const int32_t* x, const int32_t* y, int B, int 
  * cmp_train_metrics (no host sync in the step itself). */
 int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, float lr);
 int cmp_train_metrics(cmp_model* m, float* loss, float* acc);        /* syncs; last step's values */
+/* Diagnostic (bench.py `default_cfg.launches`): the kernel launches (and memset / copy nodes) ONE train step of this shape enqueues,
+ * counted on a stream capture of the step that is then dropped -- nothing executes, no state changes.  Single-process models only. */
+int cmp_train_step_launches(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others);
 /* Pipelined host-buffer step for the train loop (transformer.py:914-946): x/y are copied to pinned staging and uploaded on a
  * copy stream while earlier steps compute; returns at once with a ticket.  cmp_train_metrics_wait blocks until THAT step has
  * finished and returns its loss/accuracy.  At most 3 steps are in flight (a 4th submit waits for the oldest). */
@@ -196,7 +199,8 @@ int cmp_k_sample(void* stream, const float* logits, int V, float temperature, ui
 int cmp_prof_begin(int cls);
 int cmp_prof_end(double* total_ms, int64_t* launches, double* work);
 /* the same, and the summed ALGORITHMIC HBM bytes of those launches (every operand read once, every result written once):
- * what bench.py's per-class `algorithmic_bytes` is, next to the PMC-measured `traffic`.  Class 8 = layernorm backward. */
+ * what bench.py's per-class `algorithmic_bytes` is, next to the PMC-measured `traffic`.  Class 8 = layernorm backward.
+ * Class 9 = the decoder-block stack of a forward pass as ONE span (work = L * (24 E^2 + 2 E T) flops per token). */
 int cmp_prof_end2(double* total_ms, int64_t* launches, double* work, double* bytes);
 /* between begin and end: stop / continue recording (what has been recorded stays); bench.py times a subset of its timed steps */
 int cmp_prof_pause(void);

@@ -38,3 +38,26 @@ def test_the_integration_md_stub_runs_as_written():
     ids = ns["generate"](x[0, :10], 16, temperature=0.0)
     assert len(ids) == 16 and ((ids >= 0) & (ids < 390)).all()
     ref.close()
+
+
+def test_bench_under_the_launcher_reports_the_gradient_exchange():
+    """`bench.py --gpus 1` under torch.distributed.run takes the product's RCCL path (one-rank communicator,
+    per-block buckets on the priority stream, Adam per bucket) and its JSON line carries `comm`; the default N=1 run embeds the same
+    through a child process as `dp1` (bench.py: dp1_child) -- here the launched form itself, small and quick."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                        "--batch", "32", "--no-extras", "--no-cpu-baseline", "--no-decode"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    doc = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    comm = doc["comm"]
+    assert comm["ranks"] == 1 and comm["steps"] == 4 and comm["buckets"] == 6 + 2 + 1          # L blocks + ln_f + embeddings, + the metrics message
+    assert comm["bytes"] > 4 * 19e6 * 0.9                                                          # every fp32 gradient once
+    assert 0.0 <= comm["exposed_ms"] / comm["steps"] < 0.5 * doc["ms_per_step"]

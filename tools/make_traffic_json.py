@@ -86,7 +86,11 @@ def main():
     doc["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --no-extras "
                      "--no-cpu-baseline --no-decode` itself: bytes at the L2's memory side per launch INSIDE the train step; FETCH_SIZE "
                      "doubled (gfx950 tallies 128-byte requests at 64 bytes); classes as in bench.py's `classes` table")
-    doc.setdefault("runs", {})[key] = {"steps_sampled": steps, "classes": classes, "kernels": kernels}
+    # the library the passes ran on: bench.py prints a run's traffic only while the loaded library still has this key
+    import ctypes, os
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "composer_amd", "lib", "libcomposer_hip.so"))
+    lib.cmp_build_key.restype = ctypes.c_char_p
+    doc.setdefault("runs", {})[key] = {"steps_sampled": steps, "build_key": lib.cmp_build_key().decode(), "classes": classes, "kernels": kernels}
     json.dump(doc, open(path, "w"), indent=1)
     print(key, {c: round(v["traffic_bytes_per_launch"] / 1e6, 1) for c, v in classes.items()})
 
