@@ -176,3 +176,65 @@ def test_bf16_emulation_rounds_to_nearest_even_and_keeps_the_formulas():
     c = O.OracleTransformer(cfg, params, seed=3, emulate_bf16=True)
     lc, _, Gc, _ = c.loss_and_grads(x, y, training=True, step=2)
     assert 1e-6 < abs(lc - la) < 5e-2 * la
+
+
+# ---------------------------------------------------------------------------------------------- oracle/run_tf_reference.py
+def test_run_tf_reference_names_every_parameter_of_the_goldens():
+    """The script that would pin the oracle to TensorFlow assigns the goldens' weights through the reference's object graph: its
+    name -> attribute-path table must cover exactly the goldens' parameter names (no TensorFlow needed for this part)."""
+    from oracle import run_tf_reference as R
+    for name in ("gA", "gB", "gC"):
+        g, cfg, params = load_golden(name)
+        assert set(R.reference_variable_paths(cfg.L)) == set(params), name
+        assert set(R.golden_params(g)) == set(params)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/composer"), reason="the reference tree exists in the build container only")
+def test_run_tf_reference_attribute_paths_exist_in_the_reference_source():
+    """Every attribute the script dereferences on the reference model is assigned in the reference's source: `self.<attr> =` in the
+    class it is looked up on (transformer.py:117,189-190,257-270,482-495,551-571,673-694) -- read with ast, nothing is imported."""
+    import ast
+    from oracle import run_tf_reference as R
+    tree = ast.parse(open("/root/reference/composer/models/transformer.py").read())
+    assigned = {}
+    for cls in [n for n in ast.walk(tree) if isinstance(n, ast.ClassDef)]:
+        attrs = set()
+        for n in ast.walk(cls):
+            if isinstance(n, ast.Attribute) and isinstance(n.ctx, ast.Store) and isinstance(n.value, ast.Name) and n.value.id == "self":
+                attrs.add(n.attr)
+        assigned[cls.name] = attrs
+    owner = {"wte": "Transformer", "wpe": "Transformer", "ln_f": "Transformer", "decoder_blocks": "Transformer",
+             "ln_1": "DecoderBlock", "ln_2": "DecoderBlock", "attn": "DecoderBlock", "mlp": "DecoderBlock",
+             "c_attn": "Attention", "c_fc": "MultilayerPerceptron"}
+    for path in R.reference_variable_paths(2).values():
+        for i, step in enumerate(path[:-1]):
+            if isinstance(step, int):
+                continue
+            if step == "c_proj":
+                cls = "Attention" if "attn" in path else "MultilayerPerceptron"
+            else:
+                cls = owner[step]
+            assert step in assigned[cls], (step, cls)
+        leaf, parent = path[-1], path[-2]
+        if parent in ("c_attn", "c_proj", "c_fc"):
+            assert leaf in assigned["Conv1D"], leaf                      # weight, bias (Conv1D.build)
+        elif parent == "wte":
+            assert leaf in assigned["SharedTokenEmbedding"], leaf        # weight
+        else:
+            assert leaf in ("gamma", "beta", "embeddings")               # Keras LayerNormalization / Embedding variables
+
+
+def test_run_tf_reference_reports_unpinned_without_tensorflow_or_pins_with_it(tmp_path):
+    """Exit status 3 = TensorFlow not importable (this container, the GPU box): parity stays "unpinned".  With TensorFlow AND the
+    reference tree present the same call runs every comparison and must return 0."""
+    from oracle import run_tf_reference as R
+    try:
+        import tensorflow  # noqa: F401
+        have_tf = True
+    except Exception:
+        have_tf = False
+    rc = R.main(["--out", str(tmp_path / "tf"), "--golden", "gA"])
+    if have_tf and os.path.isdir("/root/reference/composer"):
+        assert rc == 0
+    else:
+        assert rc == 3
