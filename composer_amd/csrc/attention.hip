@@ -496,7 +496,14 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
     const float inv_scale = 1.0f / scale;           // throughput mode works on raw scores: the mask term goes in divided by the scale
 
     for (int ph = 0; ph < 2; ph++) {
+#ifdef ATTN_LIGHT_FIRST
+        // the pair's LIGHT query block first: the four pair-workgroups of a (batch, head) row then start on key tile 0 together and
+        // their heavy blocks follow one tile apart -- a sliding window of the row's K/V stays in the XCD's L2 instead of the light
+        // blocks re-reading the first tiles long after the heavy ones streamed past them
+        const int qb = qb1 < 0 ? (ph == 0 ? qb0 : -1) : (ph == 0 ? qb1 : qb0);
+#else
         const int qb = ph == 0 ? qb0 : qb1;
+#endif
         if (qb < 0) break;
         const int q0w = qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
@@ -1434,7 +1441,14 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
     const float keep_scale = DROP ? drop.scale : 1.0f;
 
     for (int ph = 0; ph < 2; ph++) {
+#ifdef ATTN_LIGHT_FIRST
+        // the pair's LIGHT query block first: the four pair-workgroups of a (batch, head) row then start on key tile 0 together and
+        // their heavy blocks follow one tile apart -- a sliding window of the row's K/V stays in the XCD's L2 instead of the light
+        // blocks re-reading the first tiles long after the heavy ones streamed past them
+        const int qb = qb1 < 0 ? (ph == 0 ? qb0 : -1) : (ph == 0 ? qb1 : qb0);
+#else
         const int qb = ph == 0 ? qb0 : qb1;
+#endif
         if (qb < 0) break;
         const int q0w = qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);

@@ -1173,10 +1173,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         __syncthreads();      // stage 0 of this item has landed (vmcnt(0) rides on the barrier); previous epilogue left stage 1
         bf16x8 diag_a[2][2][4], diag_b[2][4];       // GEMM_DIAG 2 / 4 only
         if (!run) kt1 = kt0;                        // (nothing of the scheduler inside the k-loop, see ItemPuller)
+#ifdef GEMM_EARLY_SLAB
+        // Static striding, an even number of k-steps (the last one computes out of stage 1, stage 0 is free by then): the NEXT
+        // item's first k-slab is issued at the top of this item's LAST k-step, like any other stage, instead of behind the loop.
+        // Memory reads are delivered in issue order, so with the slab issued just in front of the epilogue every operand load of
+        // the epilogue (residual, gelu' input, bias) waited until the slab had landed; a k-step earlier it has landed by then.
+        // Not for the fold kinds: their LDS-DMA image must be requested in front of the slab and lives in stage 1.
+        constexpr bool EARLY_OK = SWAP && !((LNM & 1) != 0 && EPI != EPI_RESID && EPI != EPI_GENERIC);
+        const bool early = EARLY_OK && !pl.ctr && run && ((kt1 - kt0) & 1) == 0 && kt1 > kt0 && item + (int)gridDim.x < nitems;
+        int m0n = 0, n0n = 0, kt0n = 0, kt1n = 0;
+        __amdgpu_buffer_rsrc_t ran = ra, rbn = rb;
+        if (early) {
+            item_coords(item + gridDim.x, m0n, n0n, kt0n, kt1n);
+            ran = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0n);
+            rbn = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0n);
+        }
+#else
+        constexpr bool early = false;
+#endif
         for (int kt = kt0; kt < kt1; kt++) {
             const int st = (kt - kt0) & 1;
             const char* ia = smem + st * 2 * H_IMG;
             const char* ib = ia + H_IMG;
+#ifdef GEMM_EARLY_SLAB
+            if (early && kt + 1 == kt1) {
+                glds_tile256<A_KM, A_AUX>(ran, smem, lda * 2, kt0n * G_BK, wave, lane);
+                glds_tile256<B_KM>(rbn, smem + H_IMG, ldb * 2, kt0n * G_BK, wave, lane);
+            }
+#endif
             // GEMM_DIAG (measurement builds only -- the results are wrong; tools/ubench/gemm_latency_probe.py):
             // 1 = no MFMA (fragment reads kept alive), 2 = no LDS fragment reads (the first step's fragments reused),
             // 3 = no DMA inside the k-loop, 4 = neither reads nor DMA (MFMA + barrier only), 5 = as 1 with TWO stage loads per step
@@ -1292,7 +1316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
-            if (kt0 < kt1) {
+            if (kt0 < kt1 && !early) {          // (early: that slab went out in front of the last k-step)
                 glds_tile256<A_KM, A_AUX>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
             }
@@ -2073,7 +2097,20 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
             for (int tm = 0; tm < cdiv(probs[i].M, 256); tm++)
                 for (int tn = 0; tn < cdiv(probs[i].N, 256); tn++) tiles.push_back({i, tm * 256, tn * 256});
         const int T = (int)tiles.size(), nk = K / P_BK;
-        const int sp = std::max(1, std::min(G / T, nk));
+        // Split count: every split of every tile is one more partial 256x256 f32 tile through the float-atomic unit (~1.3 TB/s),
+        // every split less is a longer k-loop per workgroup.  With few tokens the atomics win: the reference's default configuration
+        // (1 024 tokens, 12 tiles) ran 21 splits = 64 MB of atomics for 32 k-steps of work, 44 us per block; the minimum of
+        //   ceil(nk / s) * 0.91 us + T * s * 256 KiB / 1.3 TB/s          (tools/kbench.py wgradgroup, same constants as below)
+        // over s <= G / T is 4 splits there (~17 us) and stays at G / T for the benchmark shapes (K = 32 768 ... 131 072 tokens).
+        int sp = 1;
+        {
+            const int smax = std::max(1, std::min(G / T, nk));
+            double best = 1e30;
+            for (int c = 1; c <= smax; c++) {
+                const double t = (double)cdiv(nk, c) * 0.91 + (double)T * c * 262144.0 / 1.3e6;
+                if (t < best * 0.999) { best = t; sp = c; }
+            }
+        }
         // Workgroups left over by the common split count (C2: 256 - 48 * 5 = 16) go to whole PROBLEMS, smallest first, as one
         // more split each (tiles that share operand panels keep the same K ranges): their items are shorter, finish early and
         // put their share of the atomic traffic out before the final burst; the longest item is unchanged.
