@@ -639,9 +639,10 @@ __device__ __forceinline__ void epi_prefetch(const Epilogue& ep, int row0, int c
         for (int c = 0; c < NPRE; c++) pre.opnd[c] = epi_opnd<KIND, LNM>(ep, row0, col, c, rl);
     }
 }
-template <int KIND, bool XOR_STG, int LNM = 0, int NP = 1, int NPRE = 2>
+// NI = 16-row groups of the wave's tile: 8 (128 rows: the 256x256 kernels), 4 (64 rows: the 128x128 kernel)
+template <int KIND, bool XOR_STG, int LNM = 0, int NP = 1, int NPRE = 2, int NI = 8>
 __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict__ C, int ldc, int row0, int col, float* stg,
-                                         int lane, const f32x4 (&acc)[8][4], EpiPre<KIND, LNM, NP>& pre, f32x2* lstat = nullptr,
+                                         int lane, const f32x4 (&acc)[NI][4], EpiPre<KIND, LNM, NP>& pre, f32x2* lstat = nullptr,
                                          f32x2* lrow = nullptr, const char* fold_vec = nullptr) {
     constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
     constexpr bool LN_IN = (LNM & 1) != 0, LN_OUT = (LNM & 2) != 0;
@@ -674,7 +675,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
+    for (int c = 0; c < 2 * NI; c++) {
         const int i = c >> 1, it = c & 1;
         if (it == 0) {
 #pragma unroll
@@ -687,7 +688,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
                 }
             }
         }
-        if (LOADS && c + NPRE < 16) pre.opnd[c + NPRE] = epi_opnd<KIND, LNM>(ep, row0, col, c + NPRE, rl);
+        if (LOADS && c + NPRE < 2 * NI) pre.opnd[c + NPRE] = epi_opnd<KIND, LNM>(ep, row0, col, c + NPRE, rl);
         const int r16 = it * 8 + rl;
         f32x4 v0, v1;
         if (XOR_STG) {
@@ -810,15 +811,15 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
     }
 }
 // the kind a launch may use (full tiles only; everything else takes the generic run-time epilogue)
-static int epi_kind_of(const Epilogue& ep, int M, int N, bool swap, bool slabs) {
-    if (!swap || slabs || ep.out_fp32 || ep.dbg_nostore || ep.atomic || M % 256 || N % 256) return EPI_GENERIC;
+static int epi_kind_of(const Epilogue& ep, int M, int N, bool swap, bool slabs, int tile = 256) {
+    if (!swap || slabs || ep.out_fp32 || ep.dbg_nostore || ep.atomic || M % tile || N % tile) return EPI_GENERIC;
     if (ep.act == 1) return (!ep.resid && !ep.drop.thr) ? EPI_GELU_AUX : EPI_GENERIC;
     if (ep.act == 2) return (!ep.resid && !ep.drop.thr && !ep.bias) ? EPI_GELUGRAD : EPI_GENERIC;
     if (ep.resid) return EPI_RESID;
     return ep.drop.thr ? EPI_GENERIC : EPI_PLAIN;
 }
 
-template <bool A_KM, bool B_KM, bool SWAP>
+template <bool A_KM, bool B_KM, bool SWAP, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
                                                                 Epilogue ep, int ktiles_per_split, int tiles_n, int ntiles) {
@@ -889,6 +890,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
         // 64x64 fp32 tile, 32 rows at a time, in a private [32][68]-float region (b128 writes and reads conflict-free),
         // then every lane finishes 8 consecutive columns of one row: bias/aux/residual/output are all 16-byte,
         // row-contiguous accesses (8 lanes = one full 128-B line of bf16).
+        if constexpr (EPI != EPI_GENERIC) {
+            // whole 128x128 tiles: the compile-time kinds of the persistent kernels (straight-line chunks, stores fire-and-forget,
+            // fused bias-gradient column sums) -- the run-time epilogue below waits out a store round trip per chunk, which at the
+            // reference's default configuration (1 024 tokens: 16-64 tiles per GEMM) was a third of a 12 us launch
+            float* stg16 = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+            const int col = n0 + wn * 64 + (lane & 7) * 8;
+            EpiPre<EPI, 0, 1> pre;
+            epi_prefetch<EPI, 0, 1, 2>(ep, m0 + wm * 64, col, lane, pre);
+            epi_tile<EPI, false, 0, 1, 2, 4>(ep, (bf16_t*)C, ldc, m0 + wm * 64, col, stg16, lane, acc, pre);
+            return;
+        }
         float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -1107,11 +1119,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
     // rows the NEXT GEMM folds a LayerNorm into: their A stream is non-temporal (aux = 2) and their output stores default-policy,
     // so the consumer finds its A operand in the Infinity Cache instead of HBM (a fold GEMM on a cold A: +30...+100 us per launch
     // at C2, tools/chain_bench.py; inference forward of C2 7.51 -> 7.22 ms same-box with both, profiles/r5_01_ln_fused.txt).
-#ifdef XA_NT_ALL
-    constexpr int A_AUX = 2;
-#else
-    constexpr int A_AUX = (EPI == EPI_RESID && LNM != 0) ? 2 : 0;
-#endif
+    constexpr int A_AUX = (EPI == EPI_RESID && LNM != 0) ? 2 : 0;     // (either c_proj kind alone measured worse than both: r5_01)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -1995,12 +2003,22 @@ static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, 
 }
 
 template <bool A_KM, bool B_KM>
-static void launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M, int N, int K, const bf16_t* a, int lda,
+static bool launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M, int N, int K, const bf16_t* a, int lda,
                         const bf16_t* b, int ldb, void* C, int ldc, const Epilogue& ep, int per, int tiles_n, int ntiles) {
+    if constexpr (A_KM && B_KM) {        // forward (transposed weight shadow) and dgrad layout
+        static const bool kinds_on = [] { const char* e = getenv("COMPOSER_GEMM_FAST_KINDS"); return !(e && e[0] == '0'); }();
+        const int kind = (kinds_on && grid.y == 1) ? epi_kind_of(ep, M, N, swap, false, 128) : EPI_GENERIC;
+        auto go = [&](auto kern) { kern<<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles); };
+        if (kind == EPI_PLAIN) { go(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_PLAIN>); return true; }
+        if (kind == EPI_RESID) { go(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_RESID>); return true; }
+        if (kind == EPI_GELUGRAD) { go(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_GELUGRAD>); return true; }
+        if (kind == EPI_GELU_AUX) { go(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_GELU_AUX>); return true; }
+    }
     if (swap)
         gemm_bf16_fast_kernel<A_KM, B_KM, true><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
     else
         gemm_bf16_fast_kernel<A_KM, B_KM, false><<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+    return false;
 }
 
 // =================================================================================================
@@ -2374,8 +2392,9 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             const int tiles_n = cdiv(N, G_BN), ntiles = tiles_n * cdiv(M, G_BM);
             dim3 g1(ntiles, cdiv(nk, per));
             const bool swap = !ep.atomic;
+            ep.colsum = colsum_out;           // (fused by the compile-time kinds only; the run-time epilogue ignores it)
             if (!ta && !tb) launch_fast<true, false>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
-            else if (!ta && tb) launch_fast<true, true>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
+            else if (!ta && tb) colsum_fused = launch_fast<true, true>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
             else if (ta && !tb) launch_fast<false, false>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
             else launch_fast<false, true>(s, g1, smem, swap, M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles);
         } else
