@@ -359,15 +359,27 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int chunks = E / VN;
-    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
-        const T* xr = x + (int64_t)row * E;
-        Vec16<T> v[MAXI];
+    // the NEXT row of this wave is requested before the current one is reduced and written (two rows in flight per wave: with one,
+    // the ~8 000 resident waves keep 8 MB in flight, which is what 5 TB/s needs -- the kernel sat at 0.62 of the HBM peak)
+    const int stride = gridDim.x * wpb;
+    int row = blockIdx.x * wpb + (threadIdx.x >> 6);
+    Vec16<T> v[MAXI], nx[MAXI];
+    auto fetch = [&](int r, Vec16<T> (&dst)[MAXI]) {
+#pragma unroll
+        for (int i = 0; i < MAXI; i++) {
+            const int c = lane + 64 * i;
+            if (c < chunks) dst[i] = ld16(x + (int64_t)r * E + c * VN);
+        }
+    };
+    if (row < rows) fetch(row, v);
+    for (; row < rows; row += stride) {
+        const bool more = row + stride < rows;
+        if (more) fetch(row + stride, nx);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXI; i++) {
             int c = lane + 64 * i;
             if (c < chunks) {
-                v[i] = ld16(xr + c * VN);
 #pragma unroll
                 for (int j = 0; j < VN; j++) s += v[i].get(j);
             }
@@ -403,6 +415,10 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
         if (lane == 0) {
             mean[row] = mu;
             rstd[row] = rs;
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < MAXI; i++) v[i] = nx[i];
         }
     }
 }

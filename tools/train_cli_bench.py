@@ -10,7 +10,7 @@ import numpy as np, yaml
 from composer_amd import cli, dataset as D
 
 B, T = int(os.environ.get("TB_B", "128")), 1024
-N1, N2 = 20, 220           # 200 steps of difference: a 0.1 s start-up jitter is 0.5 ms/step (10 / 50 gave +-2.5)
+N1, N2 = 40, 440           # 400 steps of difference: a 0.1 s start-up jitter is 0.25 ms/step
 tmp = tempfile.mkdtemp(prefix="cli_bench_")
 try:
     os.makedirs(os.path.join(tmp, "data", "train"))
