@@ -19,13 +19,11 @@ line = "pytest -m gpu: tests=%s failures=%s errors=%s skipped=%s time=%ss" % tup
 open(o + "/pytest_gpu_tail.txt", "w").write(line + "\n")
 print(line)
 PY
-# 1. the default bench line (driver form)
-timeout 900 python3 bench.py > $out/bench_c2.json 2> $out/bench_c2.err
-# 2. kernel-trace statistics of the bench command (C2 at B=128, C2 at B=32, C4)
+# 1. kernel-trace statistics of the bench command (C2 at B=128, C2 at B=32, C4)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2 -o k -- $BENCH --steps 10 --warmup 3 > $out/stats_c2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2b32 -o k -- $BENCH --batch 32 --steps 10 --warmup 3 > $out/stats_c2b32.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c4 -o k -- $BENCH --config c4 --steps 6 --warmup 2 > $out/stats_c4.log 2>&1
-# 3. HBM-side traffic of every kernel class INSIDE the step: FETCH_SIZE and WRITE_SIZE in separate passes over bench.py itself
+# 2. HBM-side traffic of every kernel class INSIDE the step: FETCH_SIZE and WRITE_SIZE in separate passes over bench.py itself
 for cfg in "c2 128 131072" "c2 32 32768" "c4 32 65536"; do
   set -- $cfg
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -33,6 +31,11 @@ for cfg in "c2 128 131072" "c2 32 32768" "c4 32 65536"; do
   done
   python3 tools/make_traffic_json.py $1_tokens$3 $out/pmc_$1_$2_FETCH_SIZE $out/pmc_$1_$2_WRITE_SIZE $out/hbm_traffic.json
 done
+# ... into profiles/ BEFORE the bench line below is taken, so that line carries the traffic of THIS library build (bench.py prints a
+# run's traffic only while its build key is the loaded library's)
+cp $out/hbm_traffic.json profiles/hbm_traffic.json
+# 3. the default bench line (driver form)
+timeout 900 python3 bench.py > $out/bench_c2.json 2> $out/bench_c2.err
 # 4. MFMA-pipe busy cycles per kernel at C4 (north_star: "rocprof MFMA util"): SQ counters, their own run
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_c4 -o k -- $BENCH --config c4 --steps 3 --warmup 1 > $out/pmc_c4.log 2>&1
 python3 tools/pmc_summary.py $out/pmc_c4 > $out/pmc_c4_sq_summary.txt
