@@ -240,7 +240,9 @@ class Transformer:
     # ------------------------------------------------------------------ forward / steps
     @staticmethod
     def _ids(x):
-        a = np.ascontiguousarray(np.asarray(x).astype(np.int32))
+        a = np.asarray(x)
+        if a.dtype != np.int32 or not a.flags.c_contiguous:         # (an int32 C-ordered batch is handed over as it is: no copy per step)
+            a = np.ascontiguousarray(a.astype(np.int32))
         if a.ndim == 1:
             a = a[None]
         if a.ndim != 2:
@@ -248,7 +250,8 @@ class Transformer:
         return a
 
     def _check_ids(self, a):
-        if a.size and (a.min() < 0 or a.max() >= self.vocab_size):
+        # one pass: a negative id is a huge unsigned one
+        if a.size and int(a.view(np.uint32).max()) >= self.vocab_size:
             raise ValueError('token id outside [0, %d)' % self.vocab_size)
 
     def __call__(self, inputs, past=None, attention_mask=None, token_type_ids=None, position_ids=None,
