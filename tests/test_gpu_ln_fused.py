@@ -326,3 +326,48 @@ def test_fused_forward_logits_match_the_oracle_rows():
         want = np.asarray(orc.forward(x[b:b + 1])[0])
         got = np.asarray(logits)[b:b + 1]
         assert np.abs(got - want).max() <= 3e-2 * np.abs(want).max(), b
+
+
+def test_fused_forward_under_a_communicator_takes_items_dynamically():
+    """In a data-parallel job the persistent GEMMs claim their items from per-XCD counters (RCCL kernels may hold CUs); the fold
+    epilogues' hand-counted wait for their LDS-DMA image must hold on that path too: evaluation on a one-rank communicator equals the
+    plain run bit for bit (same kernels, same order of every sum)."""
+    from composer_amd.transformer import Transformer
+    E, H, L, T, B = 512, 8, 2, 256, 96
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, T, L, seed=11, stddev=0.05).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(3), V, B, T)
+    out = []
+    for dp in (False, True):
+        m = _model(E, H, L, T, B, 0.0)
+        m.set_weights(params)
+        if dp:
+            m.init_data_parallel(0, 1, Transformer.new_unique_id())
+        logits = m(x, training=False)[0]
+        assert _fused(m)[0] == 1
+        out.append((np.asarray(logits).copy(), m.evaluate([(x, y)])))
+        m.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
+
+
+def test_counting_the_launches_of_a_step_changes_nothing():
+    """cmp_train_step_launches captures one step on the stream, counts the graph's kernel nodes and drops it: the model's
+    trajectory is the one of a model that was never asked."""
+    from composer_amd import _lib
+    E, H, L, T, B = 256, 16, 2, 256, 2
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, T, L, seed=2, stddev=0.05).items()}
+    x, y = O.synthetic_batch(np.random.default_rng(5), V, B, T)
+    xd, yd = torch.as_tensor(x).cuda(), torch.as_tensor(y).cuda()
+    traj = []
+    for count in (False, True):
+        m = _model(E, H, L, T, B, 0.1)
+        m.set_weights(params)
+        losses = [m.train_step(x, y, 1e-3)[0]]
+        if count:
+            nk, no = C.c_int(0), C.c_int(0)
+            _lib.check(_lib.load().cmp_train_step_launches(m._h, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), B, T, C.byref(nk), C.byref(no)))
+            assert 30 < nk.value < 200 and no.value >= 1, (nk.value, no.value)
+        losses += [m.train_step(x, y, 1e-3)[0] for _ in range(3)]
+        traj.append(losses)
+        m.close()
+    assert np.allclose(traj[0], traj[1], rtol=2e-3), traj        # (bf16 + float atomics: not bitwise)
