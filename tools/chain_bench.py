@@ -51,4 +51,10 @@ for name, w in (("LayerNorm kernel", w_ln), ("GEMM, non-temporal stores", w_gemm
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); consumer(); e1.record(); torch.cuda.synchronize()
         if i >= 2: ts.append(e0.elapsed_time(e1) * 1e3)
-    print("A written by %-28s: c_fc %.1f us (min %.1f)" % (name, float(np.median(ts)), min(ts)))
+    # the writer's own time, alone
+    wt = []
+    for i in range(8):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); w(); e1.record(); torch.cuda.synchronize()
+        if i >= 2: wt.append(e0.elapsed_time(e1) * 1e3)
+    print("A written by %-28s: c_fc %.1f us (min %.1f)   writer itself %.1f us" % (name, float(np.median(ts)), min(ts), float(np.median(wt))))
