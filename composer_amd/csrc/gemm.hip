@@ -714,7 +714,12 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
                 // bias' and the column sums are re-read from the wave's DMA image for every chunk (sixteen registers less across the
                 // epilogue: with them held, the GELU fold kind at 3 segments went over 256 registers and hipcc put a full
                 // `s_waitcnt vmcnt(0)` at the top of its k-step -- c_fc of C4 372 us against 318 unfused)
-                const volatile f32x4* vb = reinterpret_cast<const volatile f32x4*>(fold_vec) + (lane & 7) * 2;
+                // (the offset is made opaque per chunk so that the sixteen chunks' reads are not merged back into registers; a
+                // `volatile` read would do that too, but hipcc puts `s_waitcnt vmcnt(0)` in front of every volatile access -- 64 full
+                // drains of the store queue per item)
+                int voff = (lane & 7) * 32;
+                asm volatile("" : "+v"(voff));
+                const f32x4* vb = reinterpret_cast<const f32x4*>(fold_vec + voff);
                 const f32x4 b0 = vb[0], b1 = vb[1], a0 = vb[16], a1 = vb[17];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
