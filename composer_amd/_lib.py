@@ -62,6 +62,7 @@ SIGNATURES = {
     "cmp_train_step_dev": (_i, [_P, _P, _P, _i, _i, _f]),
     "cmp_train_metrics": (_i, [_P, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_train_step_launches": (_i, [_P, _P, _P, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "cmp_train_step_graph_probe": (_i, [_P, _P, _P, _i, _i, C.POINTER(_i), C.POINTER(_i), _i, C.POINTER(_f)]),
     "cmp_train_step_async": (_i, [_P, _P, _P, _i, _i, _f, C.POINTER(_i64)]),
     "cmp_train_metrics_wait": (_i, [_P, _i64, C.POINTER(_f), C.POINTER(_f)]),
     "cmp_loss_and_grads": (_i, [_P, _P, _P, _i, _i, C.POINTER(_f), C.POINTER(_f)]),
@@ -108,7 +109,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
+_ADDED_LATER = {"cmp_train_step_graph_probe", "cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
 
 _lib = None
 

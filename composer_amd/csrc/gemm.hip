@@ -541,6 +541,10 @@ __device__ __forceinline__ void dma16(v4i32 srd, uint32_t lds_addr, int voff) {
 // delivered once they have landed (~2 us with the whole chip loading) -- the epilogue then starts after the slab it was meant
 // to overlap.  NPRE = operand chunks requested up front (16: all of them, the rest of the epilogue issues no load; 2: the rolling
 // form of the deep-pipeline kernels, which keep their stages in flight across the epilogue anyway).
+// operand chunks of the 256x256 kernel's epilogues requested ahead of their use (rolling)
+#ifndef EPI_AHEAD
+#define EPI_AHEAD 2
+#endif
 // experiment switches (tools/ab_build.py): default-policy stores for more kinds
 #ifndef XC_PLAIN_RESID
 #define XC_PLAIN_RESID 0
@@ -1347,8 +1351,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                     if (has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                epi_prefetch<EPI, LNM, NP, 2>(ep, cm0 + wm * 128, col, lane, pre, smem + fold_off);
-                epi_tile<EPI, false, LNM, NP, 2>(ep, (bf16_t*)C, ldc, cm0 + wm * 128, col, stg, lane, acc, pre,
+                epi_prefetch<EPI, LNM, NP, EPI_AHEAD>(ep, cm0 + wm * 128, col, lane, pre, smem + fold_off);
+                epi_tile<EPI, false, LNM, NP, EPI_AHEAD>(ep, (bf16_t*)C, ldc, cm0 + wm * 128, col, stg, lane, acc, pre,
                                                   reinterpret_cast<f32x2*>(smem + LN_STAT_OFF) + wn * 256 + wm * 128,
                                                   FOLD ? reinterpret_cast<f32x2*>(smem + fold_off)
                                                        : reinterpret_cast<f32x2*>(smem + LN_STAT_OFF + 8192) + wave * 128,

@@ -1185,7 +1185,13 @@ extern "C" int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y
 // Diagnostic: how many launches ONE train step of this shape enqueues.  The step is stream-captured (nothing executes), the nodes of
 // the captured graph are counted by type, the graph is dropped and the host-side state the enqueue touched is put back.  Not
 // available once a communicator exists (RCCL calls inside a capture).
+extern "C" int cmp_train_step_graph_probe(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others,
+                                         int replay_reps, float* replay_ms);
 extern "C" int cmp_train_step_launches(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others) {
+    return cmp_train_step_graph_probe(m, x_dev, y_dev, B, T, kernels, others, 0, nullptr);
+}
+extern "C" int cmp_train_step_graph_probe(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others,
+                                         int replay_reps, float* replay_ms) {
     CMP_REQUIRE(m && x_dev && y_dev && kernels, "train_step_launches: null argument");
     CMP_REQUIRE(!m->ctx->comm, "train_step_launches: not available with a communicator");
     HIP_CHECK(hipSetDevice(m->ctx->device));
@@ -1210,6 +1216,28 @@ extern "C" int cmp_train_step_launches(cmp_model* m, const void* x_dev, const vo
         hipGraphNodeType ty;
         if (hipGraphNodeGetType(nodes[i], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel) nk++; else no++;
     }
+    // replay_reps > 0 (measurement only): the captured step is instantiated and replayed back to back -- every replay draws the SAME
+    // dropout masks and applies Adam with the SAME iteration count (both are launch arguments frozen at capture), so the model is not
+    // a training run afterwards; what it answers is what a hipGraph of the step would cost per replay against stream launches.
+    if (replay_reps > 0 && replay_ms) {
+        hipGraphExec_t ge = nullptr;
+        hipError_t e2 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (e2 == hipSuccess) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            for (int i = 0; i < 3 && e2 == hipSuccess; i++) e2 = hipGraphLaunch(ge, s);
+            (void)hipEventRecord(a, s);
+            for (int i = 0; i < replay_reps && e2 == hipSuccess; i++) e2 = hipGraphLaunch(ge, s);
+            (void)hipEventRecord(b, s);
+            if (e2 == hipSuccess) e2 = hipEventSynchronize(b);
+            float ms = 0.f;
+            if (e2 == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+            *replay_ms = ms / (float)replay_reps;
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+            (void)hipGraphExecDestroy(ge);
+        }
+        if (e2 != hipSuccess) { (void)hipGraphDestroy(g); HIP_CHECK(e2); }
+    }
     (void)hipGraphDestroy(g);
     *kernels = nk;
     if (others) *others = no;
@@ -1227,6 +1255,10 @@ extern "C" int cmp_train_metrics(cmp_model* m, float* loss_out, float* acc_out) 
 }
 
 static int check_host_ids(cmp_model* m, const int32_t* ids, int64_t n, const char* what) {
+    // one vectorisable pass for the common case (a negative id is a huge unsigned one), the search for the offender only behind it
+    uint32_t mx = 0;
+    for (int64_t i = 0; i < n; i++) mx = std::max(mx, (uint32_t)ids[i]);
+    if (mx < (uint32_t)m->V) return CMP_OK;
     for (int64_t i = 0; i < n; i++)
         CMP_REQUIRE(ids[i] >= 0 && ids[i] < m->V, "%s: token id %d at flat index %lld is outside [0, %d)", what, ids[i], (long long)i, m->V);
     return CMP_OK;

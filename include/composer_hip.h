@@ -133,6 +133,11 @@ int cmp_train_metrics(cmp_model* m, float* loss, float* acc);        /* syncs; l
 /* Diagnostic (bench.py `default_cfg.launches`): the kernel launches (and memset / copy nodes) ONE train step of this shape enqueues,
  * counted on a stream capture of the step that is then dropped -- nothing executes, no state changes.  Single-process models only. */
 int cmp_train_step_launches(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others);
+/* The same capture, instantiated and replayed `replay_reps` times back to back: milliseconds per replay (measurement only -- every
+ * replay repeats the captured step's dropout masks and Adam iteration, the model is not a training run afterwards).  What a hipGraph of
+ * the whole step would cost against stream launches (tools/default_config_graph_probe.py). */
+int cmp_train_step_graph_probe(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others,
+                               int replay_reps, float* replay_ms);
 /* Pipelined host-buffer step for the train loop (transformer.py:914-946): x/y are copied to pinned staging and uploaded on a
  * copy stream while earlier steps compute; returns at once with a ticket.  cmp_train_metrics_wait blocks until THAT step has
  * finished and returns its loss/accuracy.  At most 3 steps are in flight (a 4th submit waits for the oldest). */
