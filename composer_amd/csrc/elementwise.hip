@@ -1030,6 +1030,41 @@ __global__ __launch_bounds__(256) void ln_fold_prep_kernel(const float* __restri
         fold[d.out_off + d.cols + c0 + tx] = P[d.b_off + c0 + tx] + b;
     }
 }
+// ... and for ln_f in front of the tied-logits matmul (transformer.py:811, 818; the weight is wte itself, [V][E], K-contiguous as it
+// is): one wave per vocabulary row v writes out[v][k] = bf16(gamma[k] * wte[v][k]), cs[v] = sum of the rounded row, bias'[v] =
+// sum_k beta[k] * wte[v][k].  cs / bias' hold `npad` entries (the tile columns beyond V read zeros).
+__global__ __launch_bounds__(256) void lnf_fold_prep_kernel(const float* __restrict__ wte, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ out, float* __restrict__ cs,
+                                                            float* __restrict__ bias, int V, int E, int npad) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int v = blockIdx.x * wpb + (threadIdx.x >> 6); v < npad; v += gridDim.x * wpb) {
+        float a = 0.f, b = 0.f;
+        if (v < V) {
+            for (int k = lane * 4; k < E; k += 256) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wte + (int64_t)v * E + k);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k), be = *reinterpret_cast<const f32x4*>(beta + k);
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    o[j] = (bf16_t)(g[j] * w[j]);
+                    a += (float)o[j];
+                    b = fmaf(be[j], w[j], b);
+                }
+                *reinterpret_cast<bf16x4*>(out + (int64_t)v * E + k) = o;
+            }
+        }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (lane == 0) { cs[v] = a; bias[v] = b; }
+    }
+}
+int lnf_fold_prep_run(void* stream, const float* wte, const float* gamma, const float* beta, void* out, float* cs, float* bias, int V, int E,
+                      int npad) {
+    CMP_REQUIRE(E % 4 == 0 && npad >= V, "lnf_fold_prep: E=%d npad=%d", E, npad);
+    lnf_fold_prep_kernel<<<cdiv(npad, 4), 256, 0, (hipStream_t)stream>>>(wte, gamma, beta, (bf16_t*)out, cs, bias, V, E, npad);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
 int ln_fold_prep_run(void* stream, const float* P, void* ST, float* fold, const void* desc_dev, int ndesc, int max_cols) {
     if (ndesc <= 0) return CMP_OK;
     ln_fold_prep_kernel<<<dim3(cdiv(max_cols, 32), ndesc), 256, 0, (hipStream_t)stream>>>(P, (bf16_t*)ST, fold, (const FoldDesc*)desc_dev);

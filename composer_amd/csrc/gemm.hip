@@ -35,6 +35,7 @@ struct Epilogue {
     uint32_t* sched_clear; // ... and the counter set the NEXT launch on this stream will draw from (zeroed by this one)
     LnEpi ln;              // LayerNorm fused into the epilogue (compile-time kinds of the forward layout only, see common.h)
     int rev;               // persistent 256x256 kernel: every XCD group walks its run of tiles from the END (see item_coords)
+    int n_cols;            // EPI_PLAIN32: live output columns (the last tile column may be ragged)
 };
 
 template <typename T, bool EXACT>
@@ -499,7 +500,9 @@ __device__ __forceinline__ void epi_finish8(const Epilogue& ep, void* C, int ldc
 // tile, the store round trip serialised 16 times).  A kind fixes what touches memory inside the loop, the loop is
 // straight-line code, the operand loads run two chunks ahead of their use and the waits are counted: stores are
 // fire-and-forget.
-enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_AUX = 2, EPI_RESID = 3, EPI_GELUGRAD = 4 };
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_GELU_AUX = 2, EPI_RESID = 3, EPI_GELUGRAD = 4, EPI_PLAIN32 = 5 };
+//   EPI_PLAIN32  : C (fp32, ragged last tile column) = acc + bias, with the LayerNorm fold only: ln_f into the tied-logits GEMM of
+//                  the fused block path (transformer.py:811, 818)
 //   EPI_PLAIN    : C = acc (+ bias)                                  c_attn forward; dgrad without epilogue operands
 //   EPI_GELU_AUX : aux = acc + bias ; C = gelu(aux)                  c_fc forward
 //   EPI_RESID    : C = drop(acc (+ bias)) + resid                    both c_proj forward; dgrad c_attn (+ residual grad)
@@ -766,6 +769,17 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] += (float)pre.opnd[c][j];
             }
+        }
+        if constexpr (KIND == EPI_PLAIN32) {
+            float* o32 = reinterpret_cast<float*>(C) + (int64_t)row * ldc + col;
+            if (col + 8 <= ep.n_cols) {
+                __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(o32));
+                __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(o32 + 4));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (col + j < ep.n_cols) o32[j] = v[j];
+            }
+            continue;
         }
         bf16x8 o;
 #pragma unroll
@@ -1991,6 +2005,7 @@ static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, 
             // (and the rebuilt residual into) both c_proj
 #define LN_GO(KIND, LNM_, NP_) do { go(gemm_bf16_256_kernel<A_KM, B_KM, true, KIND, LNM_, NP_>); return true; } while (0)
 #define LN_NP(KIND, LNM_) do { if (ep.ln.np == 2) LN_GO(KIND, LNM_, 2); if (ep.ln.np == 3) LN_GO(KIND, LNM_, 3); } while (0)
+            if (ep.out_fp32 && lnm == 1) LN_NP(EPI_PLAIN32, 1);
             if (kind == EPI_PLAIN && lnm == 1) LN_NP(EPI_PLAIN, 1);
             if (kind == EPI_GELU_AUX && lnm == 1) LN_NP(EPI_GELU_AUX, 1);
             if (kind == EPI_RESID && lnm == 3) LN_NP(EPI_RESID, 3);
@@ -2298,6 +2313,7 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
     ep.sched = ep.sched_clear = nullptr;
     ep.ln = ex.ln;
     ep.rev = ex.rev ? 1 : 0;
+    ep.n_cols = N;
 
     const int lnm = (ex.ln.in_part ? 1 : 0) | (ex.ln.out_part ? 2 : 0);
     bool ln_done = lnm == 0;         // a launch that asks for a LayerNorm epilogue must reach a kernel that has one
@@ -2380,7 +2396,11 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
             const int g1 = std::min(ntiles * nsplit, max_wgs);
             const bool swap = !ep.atomic;
             ep.colsum = colsum_out;
-            if (lnm) {
+            if (lnm == 1 && out_fp32) {
+                // ln_f into the tied-logits GEMM: fp32 output, the last tile column may be ragged (EPI_PLAIN32)
+                ln_done = !ta && tb && swap && act == 0 && !resid && !ep.drop.thr && M % 256 == 0 && nsplit == 1 && !colsum_out && bias && ex.ln.cs &&
+                          (ex.ln.np == 2 || ex.ln.np == 3) && K == 256 * ex.ln.np;
+            } else if (lnm) {
                 const int kind = (!ta && tb) ? epi_kind_of(ep, M, N, swap, false) : EPI_GENERIC;
                 const bool in_ok = !(lnm & 1) || (ex.ln.np >= 2 && ex.ln.np <= 3 && (kind == EPI_RESID ? (ex.ln.gamma && ex.ln.beta && N == 256 * ex.ln.np)
                                                                                                      : (ex.ln.cs && bias && K == 256 * ex.ln.np)));

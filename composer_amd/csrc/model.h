@@ -114,6 +114,13 @@ struct cmp_model {
     int64_t st_version = -1;           // ... of which param_version
     bool fused_last = false;           // the forward pass whose activations are held took the fused path (its backward must too)
     void* dmask3 = nullptr;            // second MLP-branch masked gradient (fused path: alternates with dmask from block to block)
+    // ln_f folded into the tied-logits GEMM (inference passes on the fused path): the gamma-scaled copy of wte, its fold vectors
+    // (cs then bias', `lnf_npad` entries each) and the partial statistics of the last block's output rows
+    bf16_t* wte_lnf = nullptr;
+    float* lnf_fold = nullptr;
+    int lnf_npad = 0;
+    float* lnf_part = nullptr;
+    bool hf_valid = false;             // hf = ln_f(xs[L]) of the pass held has been written (cmp_hidden_get_at computes it on demand)
     int64_t iterations = 0;
     int64_t param_version = 0;         // bumped whenever a parameter value changes (cmp_param_set, Adam): the decode state's
                                        // transposed weight copies are refreshed when it has moved
@@ -210,6 +217,8 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
 int embed_fwd_stats_run(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, float* part, int B, int T,
                         int E, int pos0, float p_drop, uint64_t seed, uint32_t rng_stream);
 int ln_fold_prep_run(void* stream, const float* P, void* ST, float* fold, const void* desc_dev, int ndesc, int max_cols);
+int lnf_fold_prep_run(void* stream, const float* wte, const float* gamma, const float* beta, void* out, float* cs, float* bias, int V, int E,
+                      int npad);
 int colsum_run(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype, float* det_ws, size_t det_ws_bytes);
 int launch_metrics_reduce(hipStream_t s, const float* row_loss, const int32_t* row_correct, int rows, void* metrics);
 int launch_cast_bf16(hipStream_t s, const float* in, void* out, int64_t n);

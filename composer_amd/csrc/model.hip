@@ -346,6 +346,9 @@ static int model_create_fill(cmp_model* m, cmp_ctx* ctx, const cmp_model_cfg* cf
         CHECK_RC(dev_alloc(m, &m->wdesc_plain, wp.size() * sizeof(WDesc)));
         CHECK_RC(dev_alloc(m, &m->fdesc, fd.size() * sizeof(FoldDesc)));
         CHECK_RC(dev_alloc(m, &m->lnfold, (size_t)m->L * m->fold_stride * 4));
+        m->lnf_npad = cdiv(m->V, 256) * 256;
+        CHECK_RC(dev_alloc(m, &m->wte_lnf, (size_t)m->V * m->E * 2));
+        CHECK_RC(dev_alloc(m, &m->lnf_fold, (size_t)2 * m->lnf_npad * 4));
         HIP_CHECK(hipMemcpyAsync(m->wdesc_plain, wp.data(), wp.size() * sizeof(WDesc), hipMemcpyHostToDevice, ctx->stream));
         HIP_CHECK(hipMemcpyAsync(m->fdesc, fd.data(), fd.size() * sizeof(FoldDesc), hipMemcpyHostToDevice, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));      // wd, wp, fd are locals
@@ -550,6 +553,7 @@ static int ensure_workspace_fill(cmp_model* m, int B, int T) {
             CHECK_RC(dev_alloc(m, &a.ln2_part, (size_t)M * (E / 256) * 8));
         }
     }
+    if (ln && m->ST && E % 256 == 0) CHECK_RC(dev_alloc(m, &m->lnf_part, (size_t)M * (E / 256) * 8));
     CHECK_RC(dev_alloc(m, &m->hf, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->logits, (size_t)M * m->ldz * 4));
     CHECK_RC(dev_alloc(m, &m->dlogits, (size_t)M * m->ldz * es));
@@ -636,6 +640,8 @@ static int refresh_transposed_weights(cmp_model* m, bool fold) {
         transpose_weights_kernel<<<dim3(maxtiles, 2 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc_plain);
         KERNEL_CHECK();
         CHECK_RC(ln_fold_prep_run(m->ctx->stream, m->P, m->ST, m->lnfold, m->fdesc, 2 * m->L, 4 * m->E));
+        CHECK_RC(lnf_fold_prep_run(m->ctx->stream, m->P + m->off_wte, m->P + m->off_lnf_g, m->P + m->off_lnf_b, m->wte_lnf, m->lnf_fold,
+                                   m->lnf_fold + m->lnf_npad, m->V, m->E, m->lnf_npad));
     } else {
         transpose_weights_kernel<<<dim3(maxtiles, 4 * m->L), 256, 0, m->ctx->stream>>>(m->S, m->ST, (const WDesc*)m->wdesc);
         KERNEL_CHECK();
@@ -791,7 +797,9 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, a.r, E, W(o.fc_w), E, a.g, 4 * E, fold + 10 * E, 1, training ? a.fc : nullptr, 4 * E, nullptr,
                       0, 0, 1, 0.f, 0, RV[2], nullptr, &l));                          // g = gelu(ln_2(r).Wfc + b)    :591, 504
         l = LnEpi();
-        if (i + 1 < m->L) l.out_part = m->act[i + 1].ln1_part;                        // (ln_f runs as a kernel: it needs no partials)
+        // (the last block's statistics feed ln_f, folded into the logits GEMM on inference passes; a training pass keeps the ln_f
+        //  kernel: its output hf is an operand of the tied weight gradient)
+        l.out_part = i + 1 < m->L ? m->act[i + 1].ln1_part : (training ? nullptr : m->lnf_part);
         CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, a.g, 4 * E, W(o.pr_w), 4 * E, m->xs[i + 1], E, m->P + o.pr_b, 0, nullptr, 0, a.r, E, 0, 1, pr,
                       drop_stream(step, i, 3), RV[3], nullptr, l.out_part ? &l : nullptr));   // x = r + dropout(mlp)  :594
     }
@@ -826,8 +834,20 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
                       0, 1, pr, drop_stream(step, i, 3)));                         // x = r + dropout(mlp)   :594
     }
     PROF_STOP(9, s, (double)M * m->L * (24.0 * E * E + 2.0 * E * Tt), 0.0);        // (causal attention on the unmasked half)
+    static const bool lnf_fold_on = [] { const char* e = getenv("COMPOSER_LNF_FOLD"); return !(e && e[0] == '0'); }();
+    if (fused && !training && lnf_fold_on) {
+        // ln_f folded into the tied-logits GEMM like ln_1 / ln_2 into c_attn / c_fc (:811, 818): the raw rows of the last block
+        // against the gamma-scaled copy of wte; hf is not written (cmp_hidden_get_at computes it on demand)
+        LnEpi l;
+        l.in_part = m->lnf_part; l.np = E / 256; l.eps = m->cfg.ln_eps; l.cs = m->lnf_fold;
+        m->hf_valid = false;
+        CHECK_RC(gemm(m, 0, 1, M, m->V, E, m->xs[m->L], E, m->wte_lnf, E, m->logits, m->ldz, m->lnf_fold + m->lnf_npad, 0, nullptr, 0, nullptr,
+                      0, 1, 1, 0.f, 0, 0, nullptr, &l));
+        return CMP_OK;
+    }
     CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[m->L], m->P + m->off_lnf_g, m->P + m->off_lnf_b, m->hf, m->lnf_mean, m->lnf_rstd, M,
                                  E, m->cfg.ln_eps, dt));                           // :811 (always applied)
+    m->hf_valid = true;
     CHECK_RC(gemm(m, 0, 1, M, m->V, E, m->hf, E, m->w(m->off_wte), E, m->logits, m->ldz, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                   1, 0.f, 0));                                                     // tied logits            :818
     return CMP_OK;
@@ -1461,6 +1481,11 @@ extern "C" int cmp_hidden_get_at(cmp_model* m, int index, int B, int T, int64_t 
                 m->lastT - m->last_past, B, T);
     HIP_CHECK(hipSetDevice(m->ctx->device));
     const int64_t n = (int64_t)B * T * m->E;
+    if (index == m->L && !m->hf_valid) {        // the pass folded ln_f into its logits GEMM: the ln_f output is produced now
+        CHECK_RC(cmp_k_layernorm_fwd(m->ctx->stream, m->xs[m->L], m->P + m->off_lnf_g, m->P + m->off_lnf_b, m->hf, m->lnf_mean, m->lnf_rstd,
+                                     B * T, m->E, m->cfg.ln_eps, m->dtype));
+        m->hf_valid = true;
+    }
     const void* src = index < m->L ? m->xs[index] : m->hf;
     float* tmp = nullptr;
     CHECK_RC(io_scratch(m, 0, (size_t)n * 4, (void**)&tmp));

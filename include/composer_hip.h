@@ -273,7 +273,9 @@ int cmp_k_wgrad_group(void* stream, int nprob, const void* const* A, const int* 
  *     2..3, eps): statistics of the rows of A (fold: cs given; the GEMM's B operand is WT and its bias is bias_out) or of the
  *     rows of `resid` (gamma, beta given: the residual operand becomes LN(resid), transformer.py:587); out_part: the partials of
  *     the OUTPUT rows are written (residual epilogues).  bf16, ta=0, tb=1, M and N multiples of 256, and a shape that reaches the
- *     persistent 256x256 kernel (CMP_GEMM_TILE256 forces it); anything else fails with CMP_ERR_INVALID.
+ *     persistent 256x256 kernel (CMP_GEMM_TILE256 forces it); anything else fails with CMP_ERR_INVALID.  With out_fp32 the fold also
+ *     takes a ragged N (ln_f folded into the tied-logits matmul, transformer.py:811, 818: N = vocabulary size; cs and bias must then
+ *     hold N rounded up to 256 entries, zero beyond N).
  *   cmp_k_layernorm_bwd_parts: cmp_k_layernorm_bwd_fused (bf16) with the statistics taken from partials and the LayerNorm OUTPUT
  *     yout = xhat*gamma + beta written beside dx (the weight-gradient GEMM of the consuming Conv1D is its only reader); dmask
  *     (when given) is written whatever p_drop is. */

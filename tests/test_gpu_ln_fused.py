@@ -371,3 +371,64 @@ def test_counting_the_launches_of_a_step_changes_nothing():
         traj.append(losses)
         m.close()
     assert np.allclose(traj[0], traj[1], rtol=2e-3), traj        # (bf16 + float atomics: not bitwise)
+
+
+@pytest.mark.parametrize("E", [512, 768])
+def test_fold_epilogue_with_fp32_output_and_a_ragged_last_column(lib, E):
+    """ln_f folded into the tied-logits GEMM (transformer.py:811, 818): fp32 output, N = 390 columns in rows of 448 -- the last tile
+    column is ragged and the padding columns must stay untouched."""
+    M, N, ldc = 512, 390, 448
+    rng = np.random.default_rng(E)
+    x = bf(rng.normal(0.5, 1.5, (M, E)))
+    wte = rng.normal(0, 0.05, (N, E)).astype(np.float32)
+    g = (1 + 0.3 * rng.normal(size=E)).astype(np.float32)
+    be = rng.normal(0, 0.2, E).astype(np.float32)
+    WT = bf(g[None, :] * wte)                                         # [N, E]: the gamma-scaled copy of wte
+    wt64 = WT.double().cpu().numpy()
+    cs = f32(np.concatenate([wt64.sum(1), np.zeros(512 - N)]))
+    bias = f32(np.concatenate([wte.astype(np.float64) @ be.astype(np.float64), np.zeros(512 - N)]))
+    x64 = x.double().cpu().numpy()
+    part = f32(parts_of(x64))
+    out = torch.full((M, ldc), -3.0, dtype=torch.float32, device="cuda")
+    ck(lib, lib.cmp_gemm_ln_next(P(part), E // 256, EPS, P(cs), None, None, None))
+    ck(lib, lib.cmp_k_gemm(stream(), BF16, 0, 1, M, N, E, P(x), E, P(WT), E, P(out), ldc, P(bias), 0, None, 0, None, 0, 1, 1, 0.0, 0, 0, 8))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = ln64(x64, g.astype(np.float64), be.astype(np.float64)) @ wte.astype(np.float64).T
+    assert rel(got[:, :N], want) < 1.2e-2
+    mu, var = x64.mean(-1, keepdims=True), x64.var(-1, keepdims=True)
+    rs = 1 / np.sqrt(var + EPS)
+    exact = rs * (x64 @ wt64.T) - rs * mu * wt64.sum(1) + bias.double().cpu().numpy()[:N]
+    assert rel(got[:, :N], exact) < 2e-5                              # fp32 output: only the accumulation order is left
+    assert np.all(got[:, N:] == -3.0)
+
+
+def test_hidden_states_after_a_pass_that_folded_ln_f():
+    """output_hidden_states on the fused path: the ln_f output is not written by the pass (ln_f lives in the logits GEMM) and is
+    produced when asked for -- it must be LayerNorm(last block output) all the same."""
+    from composer_amd.transformer import Transformer
+    E, H, L, T, B = 512, 8, 2, 256, 96
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, T, L, seed=4, stddev=0.05).items()}
+    rng = np.random.default_rng(1)
+    params["ln_f/gamma"] = (1 + 0.2 * rng.normal(size=E)).astype(np.float32)
+    params["ln_f/beta"] = (0.1 * rng.normal(size=E)).astype(np.float32)
+    x, _ = O.synthetic_batch(rng, V, B, T)
+    m = Transformer(V, E, T, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="bf16", seed=3, max_batch=B, max_seq=T,
+                    output_hidden_states=True)
+    m.set_weights(params)
+    logits, _, hidden = m(x, training=False)
+    assert _fused(m)[0] == 1
+    hf = hidden[L]                                                   # hidden[i < L] are the blocks' inputs, hidden[L] the ln_f output
+    m.close()
+    os.environ["COMPOSER_LN_FUSED"] = "0"
+    try:
+        m2 = Transformer(V, E, T, L, H, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="bf16", seed=3, max_batch=B, max_seq=T,
+                         output_hidden_states=True)
+        m2.set_weights(params)
+        logits2, _, hidden2 = m2(x, training=False)
+        assert _fused(m2)[0] == 0
+        m2.close()
+    finally:
+        os.environ.pop("COMPOSER_LN_FUSED", None)
+    assert np.abs(hf - hidden2[L]).max() <= 4e-2 * np.abs(hidden2[L]).max()
+    assert np.abs(np.asarray(logits) - np.asarray(logits2)).max() <= 3e-2 * np.abs(np.asarray(logits2)).max()
