@@ -46,6 +46,7 @@ SIGNATURES = {
     "cmp_dp_unique_id": (_i, [_P]),
     "cmp_dp_init": (_i, [_P, _i, _i, _P]),
     "cmp_dp_allreduce_test": (_i, [_P, _P, _i]),
+    "cmp_dp_init_exchange": (_i, [_P, _i, _i, _P, _P]),
     "cmp_dp_test_hog": (_i, [_P, _i, _i]),
     "cmp_dp_set_gemm_cus": (_i, [_P, _i]),
     "cmp_dp_set_mask_rank": (_i, [_P, _i]),
@@ -109,7 +110,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_train_step_graph_probe", "cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
+_ADDED_LATER = {"cmp_dp_init_exchange", "cmp_train_step_graph_probe", "cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
 
 _lib = None
 

@@ -37,6 +37,10 @@ struct cmp_ctx {
     hipStream_t stream = nullptr;       // compute
     hipStream_t comm_stream = nullptr;  // RCCL
     ncclComm_t comm = nullptr;
+    // cmp_dp_init_exchange: the sum over ranks is delegated to the caller (another transport; two ranks sharing one device in tests)
+    int (*xfn)(void*, void*, int64_t, void*) = nullptr;
+    void* xuser = nullptr;
+    bool dp_on() const { return comm != nullptr || xfn != nullptr; }
     int rank = 0, nranks = 1;
     uint32_t seed_mix = 0;              // mix32(rank), xor-ed into every dropout seed: replicas draw independent masks
     int gemm_max_wgs = 0;               // cap on the persistent GEMM grids while a communicator exists (0 = all CUs)

@@ -180,7 +180,7 @@ extern "C" int cmp_dp_unique_id(void* id128) {
 }
 extern "C" int cmp_dp_init(cmp_ctx* c, int rank, int nranks, const void* id128) {
     CMP_REQUIRE(c && id128 && nranks >= 1 && rank >= 0 && rank < nranks, "dp_init: bad arguments");
-    CMP_REQUIRE(c->comm == nullptr, "dp_init: communicator already initialised");
+    CMP_REQUIRE(!c->dp_on(), "dp_init: communicator already initialised");
     HIP_CHECK(hipSetDevice(c->device));
     ncclUniqueId id;
     memcpy(&id, id128, 128);
@@ -188,6 +188,29 @@ extern "C" int cmp_dp_init(cmp_ctx* c, int rank, int nranks, const void* id128) 
     c->rank = rank;
     c->nranks = nranks;
     c->seed_mix = mix32((uint32_t)rank);      // seed ^ mix32(rank): rank 0 keeps the model seed, the others draw their own masks
+    return CMP_OK;
+}
+extern "C" int cmp_dp_init_exchange(cmp_ctx* c, int rank, int nranks, int (*fn)(void*, void*, int64_t, void*), void* user) {
+    CMP_REQUIRE(c && fn && nranks >= 1 && rank >= 0 && rank < nranks, "dp_init_exchange: bad arguments");
+    CMP_REQUIRE(!c->dp_on(), "dp_init_exchange: communicator already initialised");
+    c->xfn = fn;
+    c->xuser = user;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->seed_mix = mix32((uint32_t)rank);
+    return CMP_OK;
+}
+// sum of p[0, n) over the ranks, in place, ordered on the communication stream: RCCL, or the caller's exchange function
+static int dp_allreduce(cmp_ctx* c, float* p, size_t n) {
+    if (c->xfn) {
+        const int rc = c->xfn(c->xuser, p, (int64_t)n, (void*)c->comm_stream);
+        if (rc != 0) {
+            cmp_set_error("data-parallel exchange function failed with %d on %zu floats", rc, n);
+            return CMP_ERR_INVALID;
+        }
+        return CMP_OK;
+    }
+    NCCL_CHECK(ncclAllReduce(p, p, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
     return CMP_OK;
 }
 extern "C" int cmp_dp_set_mask_rank(cmp_ctx* c, int rank) {
@@ -219,11 +242,15 @@ extern "C" int cmp_dp_test_hog(cmp_ctx* c, int wgs, int usec) {
     return CMP_OK;
 }
 extern "C" int cmp_dp_allreduce_test(cmp_ctx* c, float* host_inout, int n) {
-    CMP_REQUIRE(c && c->comm, "dp_allreduce_test: communicator not initialised");
+    CMP_REQUIRE(c && c->dp_on(), "dp_allreduce_test: communicator not initialised");
     float* d = nullptr;
     HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
     HIP_CHECK(hipMemcpyAsync(d, host_inout, (size_t)n * 4, hipMemcpyHostToDevice, c->comm_stream));
-    NCCL_CHECK(ncclAllReduce(d, d, n, ncclFloat, ncclSum, c->comm, c->comm_stream));
+    if (const int rc = dp_allreduce(c, d, (size_t)n)) {
+        (void)hipStreamSynchronize(c->comm_stream);
+        (void)hipFree(d);
+        return rc;
+    }
     HIP_CHECK(hipMemcpyAsync(host_inout, d, (size_t)n * 4, hipMemcpyDeviceToHost, c->comm_stream));
     HIP_CHECK(hipStreamSynchronize(c->comm_stream));
     HIP_CHECK(hipFree(d));
@@ -703,8 +730,8 @@ static int gemm(cmp_model* m, int ta, int tb, int M, int N, int K, const void* A
     ex.colsum = det ? nullptr : colsum;                                // fused column sums are float atomics
     if (splitk > 1 && det) { ex.slab_ws = (float*)m->slab; ex.slab_bytes = (size_t)m->slab_bytes; }
     ex.role = m->gemm_role >= 0 ? m->gemm_role : (ta ? 2 : 1);         // forward announces 0; backward: A^T = wgrad, else dgrad
-    ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;              // leave CUs to the concurrent all-reduce kernels
-    ex.dp = m->ctx->comm != nullptr;                                   // RCCL kernels may hold CUs: dynamic item scheduling
+    ex.max_wgs = m->ctx->dp_on() ? m->ctx->gemm_max_wgs : 0;              // leave CUs to the concurrent all-reduce kernels
+    ex.dp = m->ctx->dp_on();                                   // RCCL kernels may hold CUs: dynamic item scheduling
     ex.sched = &m->ctx->gemm_sched;
     CHECK_RC(gemm_run(m->ctx->stream, m->dtype, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, act, aux, ldaux, resid, ldr,
                       out_fp32, splitk, p_drop, m->drop_seed(), rng_stream, flags, ex));
@@ -889,10 +916,10 @@ static int adam_range(cmp_model* m, hipStream_t s, int64_t begin, int64_t end, f
 // update == false: gradients only (cmp_loss_and_grads).
 static int bucket_ready(cmp_model* m, int ev, int64_t begin, int64_t end, float lr, bool update) {
     cmp_ctx* c = m->ctx;
-    if (!c->comm) return CMP_OK;
+    if (!c->dp_on()) return CMP_OK;
     HIP_CHECK(hipEventRecord(m->bucket_ev[ev], c->stream));
     HIP_CHECK(hipStreamWaitEvent(c->comm_stream, m->bucket_ev[ev], 0));
-    NCCL_CHECK(ncclAllReduce(m->G + begin, m->G + begin, (size_t)(end - begin), ncclFloat, ncclSum, c->comm, c->comm_stream));
+    CHECK_RC(dp_allreduce(c, m->G + begin, (size_t)(end - begin)));
     m->dp_bytes_step += (end - begin) * 4;
     m->dp_msgs_step += 1;
     if (update) {
@@ -1009,8 +1036,8 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                 {a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w, 3 * Ea, E, 3 * Ea}};    // dWattn = u^T . dqkv
             GemmExtra ex;
             ex.role = 2;
-            ex.max_wgs = m->ctx->comm ? m->ctx->gemm_max_wgs : 0;
-            ex.dp = m->ctx->comm != nullptr;
+            ex.max_wgs = m->ctx->dp_on() ? m->ctx->gemm_max_wgs : 0;
+            ex.dp = m->ctx->dp_on();
             ex.sched = &m->ctx->gemm_sched;
             bool handled = false;
             CHECK_RC(wgrad_group_run(s, &m->wgrad_groups[i], wp, 4, M, ex, &handled));
@@ -1065,12 +1092,12 @@ __global__ void dp_metrics_unpack_kernel(Metrics* __restrict__ mt, const float* 
 }
 static int dp_metrics_begin(cmp_model* m) {
     cmp_ctx* c = m->ctx;
-    if (!c->comm) return CMP_OK;
+    if (!c->dp_on()) return CMP_OK;
     dp_metrics_pack_kernel<<<1, 64, 0, c->stream>>>(m->metrics, m->dp_metrics);
     KERNEL_CHECK();
     HIP_CHECK(hipEventRecord(m->metrics_ev, c->stream));
     HIP_CHECK(hipStreamWaitEvent(c->comm_stream, m->metrics_ev, 0));
-    NCCL_CHECK(ncclAllReduce(m->dp_metrics, m->dp_metrics, 3, ncclFloat, ncclSum, c->comm, c->comm_stream));
+    CHECK_RC(dp_allreduce(c, m->dp_metrics, 3));
     m->dp_bytes_step = 12;          // first message of the step: the gradient buckets add theirs (bucket_ready)
     m->dp_msgs_step = 1;
     return CMP_OK;
@@ -1095,7 +1122,7 @@ static int adam(cmp_model* m, float lr) {
     cmp_ctx* c = m->ctx;
     m->iterations += 1;
     m->param_version += 1;
-    if (c->comm) {
+    if (c->dp_on()) {
         // every bucket was all-reduced AND updated on the communication stream (bucket_ready); the compute stream waits for the
         // last of them here, between two timed events: what they measure is the communication (+ last update) that the
         // backward pass did not hide -- SURVEY 8d "exposed comm time per step", read with cmp_dp_stats
@@ -1124,8 +1151,8 @@ extern "C" int cmp_dp_stats(cmp_model* m, int reset, int64_t* steps, double* exp
     CHECK_RC(dp_fold(m, -1, true));
     if (steps) *steps = m->dp_folded;
     if (exposed_ms) *exposed_ms = m->dp_exposed_ms;
-    if (bytes_per_step) *bytes_per_step = m->ctx->comm ? m->dp_bytes_step : 0;
-    if (msgs_per_step) *msgs_per_step = m->ctx->comm ? m->dp_msgs_step : 0;
+    if (bytes_per_step) *bytes_per_step = m->ctx->dp_on() ? m->dp_bytes_step : 0;
+    if (msgs_per_step) *msgs_per_step = m->ctx->dp_on() ? m->dp_msgs_step : 0;
     if (reset) { m->dp_steps = 0; m->dp_folded = 0; m->dp_exposed_ms = 0.0; }
     return CMP_OK;
 }
@@ -1175,7 +1202,7 @@ static int train_step_enqueue(cmp_model* m, const int32_t* x_dev, const int32_t*
     m->dp_buckets_updated = 0;
     int rc = backward(m, x_dev, B, T, step, true, lr, true);
     if (rc == CMP_OK) rc = adam(m, lr);
-    if (rc != CMP_OK && m->ctx->comm) {
+    if (rc != CMP_OK && m->ctx->dp_on()) {
         // Buckets already handed to the communication stream keep running (all-reduce + Adam): the compute stream must not touch
         // G / P before they are done (the next step's memset of G would race them), and a model whose buckets were partly
         // updated is no longer the model the caller thinks it has.  The failing call's message is kept.
@@ -1213,7 +1240,7 @@ extern "C" int cmp_train_step_launches(cmp_model* m, const void* x_dev, const vo
 extern "C" int cmp_train_step_graph_probe(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others,
                                          int replay_reps, float* replay_ms) {
     CMP_REQUIRE(m && x_dev && y_dev && kernels, "train_step_launches: null argument");
-    CMP_REQUIRE(!m->ctx->comm, "train_step_launches: not available with a communicator");
+    CMP_REQUIRE(!m->ctx->dp_on(), "train_step_launches: not available with a communicator");
     HIP_CHECK(hipSetDevice(m->ctx->device));
     CHECK_RC(ensure_workspace(m, B, T));
     hipStream_t s = m->ctx->stream;

@@ -212,6 +212,25 @@ class Transformer:
             _lib.check(self._lib.cmp_dp_set_gemm_cus(self._ctx, int(gemm_cus)), 'cmp_dp_set_gemm_cus')
         self._dp = (int(rank), int(world_size))
 
+    def init_data_parallel_exchange(self, rank, world_size, all_reduce):
+        """The data-parallel step over the caller's transport (cmp_dp_init_exchange): `all_reduce(dev_ptr, count, hip_stream)` must
+        leave the sum over all ranks of `count` float32 at device address `dev_ptr`, ordered on `hip_stream`; it is called once per
+        gradient bucket (and once for the 3-float metrics message), on every rank in the same order.  An exception it raises fails
+        the train step (HipLibraryError) and is kept in `self.exchange_error`."""
+        self.exchange_error = None
+
+        def _cb(user, ptr, count, stream):
+            try:
+                all_reduce(int(ptr), int(count), int(stream or 0))
+                return 0
+            except BaseException as e:          # never unwind through the C frames
+                self.exchange_error = e
+                return 1
+        self._xcb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)(_cb)     # kept alive with the model
+        _lib.check(self._lib.cmp_dp_init_exchange(self._ctx, int(rank), int(world_size), C.cast(self._xcb, C.c_void_p), None),
+                   'cmp_dp_init_exchange')
+        self._dp = (int(rank), int(world_size))
+
     def set_mask_rank(self, rank):
         """Rank folded into the dropout seed (seed ^ mix32(rank)); init_data_parallel sets it to the communicator rank."""
         _lib.check(self._lib.cmp_dp_set_mask_rank(self._ctx, int(rank)), 'cmp_dp_set_mask_rank')

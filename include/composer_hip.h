@@ -81,6 +81,16 @@ void* cmp_ctx_stream(cmp_ctx* ctx);
 int cmp_dp_unique_id(void* id128);                                   /* rank 0: fills 128 bytes */
 int cmp_dp_init(cmp_ctx* ctx, int rank, int nranks, const void* id128);
 int cmp_dp_allreduce_test(cmp_ctx* ctx, float* host_inout, int n);    /* sum over ranks, for tests */
+/* The same data-parallel step over a transport of the caller's instead of RCCL (a fabric RCCL does not drive; in tests/ two ranks
+ * that share the one GPU of a box and sum over gloo -- this image's RCCL refuses two ranks on one device).  Everything else is the
+ * path cmp_dp_init selects: the same gradient buckets in the same order, the bucket's event on the compute stream, Adam on the
+ * bucket right behind its sum on the communication stream, 1/nranks folded into the update, seed ^ mix32(rank) dropout masks,
+ * the 3-float metrics message, dynamic GEMM item scheduling.  `fn` is called on the enqueuing thread once per message, every rank
+ * in the same order: it must leave the element-wise sum over all ranks of the `count` floats at `dev_f32` (device memory) in place,
+ * ORDERED ON `hip_stream` (the communication stream, which already waits for the producers of the buffer; the function may
+ * synchronise it), and return 0; any other value fails the step (CMP_ERR_INVALID, cmp_last_error names the message size). */
+typedef int (*cmp_exchange_fn)(void* user, void* dev_f32, int64_t count, void* hip_stream);
+int cmp_dp_init_exchange(cmp_ctx* ctx, int rank, int nranks, cmp_exchange_fn fn, void* user);
 /* measurement aid: `wgs` workgroups that no persistent GEMM workgroup can share a CU with spin for `usec` microseconds on the
  * communication stream -- a stand-in for a concurrent RCCL kernel on a 1-GPU box (tools/ab_sched.sh) */
 int cmp_dp_test_hog(cmp_ctx* ctx, int wgs, int usec);

@@ -1,4 +1,11 @@
-"""-m gpu: the product data-parallel path with TWO real ranks (rank r on GPU r when the box has two; on a one-GPU box both
+"""-m gpu: the product data-parallel path with TWO real ranks.
+
+Second half of the file (always runs): both ranks share device 0 and the sum over ranks goes through the C ABI's exchange seam
+(cmp_dp_init_exchange) over gloo -- bucket order, events, per-bucket Adam on the communication stream, 1/N scaling, rank-distinct
+dropout masks, the metrics message and the dynamic GEMM scheduling of a data-parallel step all execute for world size 2 on the GPU;
+only the ncclAllReduce call itself is replaced (it runs in the 1-rank communicator tests and in bench.py's `dp1` child).
+
+First half: the same over RCCL (rank r on GPU r when the box has two; on a one-GPU box both
 ranks open device 0 and RCCL builds that refuse two ranks on one device -- this image's does -- make the test skip (the 1-rank communicator test and the two-shard emulation in
 test_gpu_model.py then remain the product-side coverage).  When it runs, rank r trains on rows [r*B, (r+1)*B) and after
 every step both ranks must hold the parameters of a single-process run on the 2B global batch, and report the same
@@ -80,3 +87,151 @@ def test_two_ranks_on_one_gpu_match_the_global_batch():
         assert np.allclose(res[0][3][n], a, atol=2e-6), n
         assert np.array_equal(res[0][3][n], res[1][3][n]), n             # replicas stay identical
     ref.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# two ranks on ONE device, summed over gloo through cmp_dp_init_exchange
+# ------------------------------------------------------------------------------------------------------------------------------
+class _Dev:                      # a device buffer handed to torch through the CUDA array interface
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
+
+
+def _gloo_exchange(calls):
+    import torch
+    import torch.distributed as dist
+
+    def all_reduce(ptr, count, stream):
+        ext = torch.cuda.ExternalStream(stream)
+        with torch.cuda.stream(ext):
+            t = torch.as_tensor(_Dev(ptr, count), device="cuda")
+            host = t.cpu()                       # waits for the producers the communication stream was made to wait for
+            dist.all_reduce(host)
+            t.copy_(host, non_blocking=False)
+        ext.synchronize()
+        calls.append(count)
+    return all_reduce
+
+
+def _xworker(rank, world, port, cfg, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from composer_amd.transformer import Transformer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        v, e, h, l, w, t, b = cfg["geom"]
+        params = {k: a.astype(np.float32) for k, a in O.init_params(v, e, w, l, seed=31).items()}
+        m = Transformer(v, e, w, l, h, attention_dropout_rate=cfg["p"], residual_dropout_rate=cfg["p"], dtype=cfg["dtype"], seed=0,
+                        max_batch=b, max_seq=w)
+        m.set_weights(params)
+        calls = []
+        m.init_data_parallel_exchange(rank, world, _gloo_exchange(calls))
+        rng = np.random.default_rng(5)
+        losses = []
+        for s in range(cfg["steps"]):
+            x, y = O.synthetic_batch(rng, v, world * b, t)
+            losses.append(m.train_step(x[rank * b:(rank + 1) * b], y[rank * b:(rank + 1) * b], 1e-3)[0])
+        stats = m.dp_stats()
+        probe = m.all_reduce_sum([1.0 + rank, 10.0])
+        out_q.put((rank, "ok", losses, {n: m.get_parameter(n) for n in m.parameter_names}, calls, stats, probe.tolist()))
+        dist.barrier()
+        m.close()
+    except BaseException as ex:                                   # the parent must not wait for the queue time-out
+        out_q.put((rank, "error", repr(ex)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_pair(cfg):
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_xworker, args=(r, 2, port, cfg, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(2):
+            res.append(out_q.get(timeout=300))
+            assert res[-1][1] == "ok", res[-1]
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    res.sort(key=lambda r: r[0])
+    return res
+
+
+def _single_process(cfg):
+    from composer_amd.transformer import Transformer
+    v, e, h, l, w, t, b = cfg["geom"]
+    params = {k: a.astype(np.float32) for k, a in O.init_params(v, e, w, l, seed=31).items()}
+    ref = Transformer(v, e, w, l, h, attention_dropout_rate=cfg["p"], residual_dropout_rate=cfg["p"], dtype=cfg["dtype"], seed=0,
+                      max_batch=2 * b, max_seq=w)
+    ref.set_weights(params)
+    rng = np.random.default_rng(5)
+    want = []
+    for s in range(cfg["steps"]):
+        x, y = O.synthetic_batch(rng, v, 2 * b, t)
+        want.append(ref.train_step(x, y, 1e-3)[0])
+    out = {n: ref.get_parameter(n) for n in ref.parameter_names}
+    ref.close()
+    return want, out
+
+
+def test_exchange_seam_two_ranks_fp32_equal_the_global_batch():
+    cfg = {"geom": (390, 64, 4, 2, 40, 40, 2), "p": 0.0, "dtype": "fp32", "steps": 3}
+    res = _run_pair(cfg)
+    want, ref = _single_process(cfg)
+    assert np.allclose(res[0][2], res[1][2], rtol=1e-6)                  # both ranks log the all-reduced mean
+    assert np.allclose(res[0][2], want, rtol=1e-5), (res[0][2], want)
+    for n, a in ref.items():
+        assert np.allclose(res[0][3][n], a, atol=2e-6), n
+        assert np.array_equal(res[0][3][n], res[1][3][n]), n             # replicas stay identical
+    # messages of a step, in order: the 3-float metrics sum, ln_f + wte/wpe ... one bucket per block in reverse, the embeddings last
+    L = cfg["geom"][3]
+    per_step = res[0][4][:L + 3]
+    assert per_step[0] == 3 and len(res[0][4]) == cfg["steps"] * (L + 3) + 1 and res[0][4] == res[1][4]
+    assert sum(per_step[1:]) == sum(a.size for a in ref.values())        # every gradient crossed exactly once (no head padding at D=16)
+    assert res[0][5]["buckets"] == L + 3 and res[0][5]["steps"] == cfg["steps"]
+    assert res[0][6] == [3.0, 20.0] and res[1][6] == [3.0, 20.0]         # cmp_dp_allreduce_test through the seam
+
+
+def test_exchange_seam_two_ranks_bf16_timed_kernels_and_dropout():
+    # E = 512, 256-row multiples: the persistent 256x256 GEMMs (dynamic item scheduling under a communicator), the grouped weight
+    # gradients and the bf16 attention kernels of the benchmark path; dropout on: the ranks draw different masks, the replicas
+    # must still end bit-identical, and the losses must follow a single-process run of the 2B batch within bf16 + mask noise
+    cfg = {"geom": (390, 512, 8, 2, 256, 256, 2), "p": 0.1, "dtype": "bf16", "steps": 4}
+    res = _run_pair(cfg)
+    want, ref = _single_process(cfg)
+    assert np.allclose(res[0][2], res[1][2], rtol=1e-6)
+    assert np.allclose(res[0][2], want, rtol=3e-2), (res[0][2], want)
+    assert res[0][2][-1] < res[0][2][0]
+    moved = 0
+    for n, a in ref.items():
+        assert np.array_equal(res[0][3][n], res[1][3][n]), n
+        assert np.all(np.isfinite(res[0][3][n])), n
+        moved += int(not np.array_equal(res[0][3][n], a))
+    assert moved > 0                                                     # other masks than the single process drew: not the same numbers
+
+
+def test_exchange_seam_failure_fails_the_step_and_poisons_the_model():
+    from composer_amd.transformer import Transformer
+    from composer_amd import _lib
+    m = Transformer(390, 64, 40, 2, 4, attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="fp32", seed=0, max_batch=2, max_seq=40)
+    seen = []
+
+    def flaky(ptr, count, stream):
+        seen.append(count)
+        if len(seen) == 3:
+            raise RuntimeError("link down")
+    m.init_data_parallel_exchange(0, 1, flaky)
+    x, y = O.synthetic_batch(np.random.default_rng(1), 390, 2, 40)
+    with pytest.raises(_lib.HipLibraryError, match="exchange function failed"):
+        m.train_step(x, y, 1e-3)
+    assert isinstance(m.exchange_error, RuntimeError)
+    with pytest.raises(_lib.HipLibraryError, match="earlier data-parallel step failed"):       # a bucket had already been updated
+        m.train_step(x, y, 1e-3)
+    m.close()
