@@ -112,26 +112,31 @@ __device__ __forceinline__ void stage_rows(T* img, const T* __restrict__ g, int6
 // Software-pipelined staging of a [64 rows][D] tile: load() issues the global loads of the NEXT tile into registers
 // before the current tile's MFMA/softmax work (latency hides under it), store() writes them to the other LDS
 // buffer afterwards -- one barrier per tile.
-template <typename T, int D> struct Stager {
-    static constexpr int VN = AT<T>::VN, DP = Geo<T, D>::DP, S = Geo<T, D>::S, CPR = DP / VN;
-    static constexpr int NC = (64 * CPR + 255) / 256;
+template <typename T, int D, int ROWS = 64> struct Stager {
+    static constexpr int VN = AT<T>::VN, DP = Geo<T, D>::DP, S = Geo<T, D>::S;
+    // 16-byte chunks per row that exist in memory.  Heads narrower than the padded width (D = 16 in bf16: DP = 32) stage only those:
+    // the padding columns of the LDS image are never written and feed nothing that is stored (mma_rows reads D columns; the d >= D
+    // rows of a transposed output tile, which mma_acc_b computes from them, are dropped by store_t_tile / colsum_t_tiles).
+    static constexpr int CPR = (D < DP ? D : DP) / VN;
+    static constexpr int NC = (ROWS * CPR + 255) / 256;
+    static constexpr bool WHOLE = (ROWS * CPR) % 256 == 0;          // every thread owns NC chunks
     Vec16<T> r[NC];
     __device__ __forceinline__ void load(const T* __restrict__ g, int64_t gstride, int row0, int row_end, int tid) {
-        if constexpr (D >= 32) {
+        if constexpr (!std::is_same<T, float>::value || D >= 32) {
             // Range-checked buffer loads: rows at or past row_end come back as zeros from the hardware, so the loads are
             // unconditional straight-line code.  (The guarded global loads they replace sat under divergent branches;
             // hipcc's wait-count pass then put s_waitcnt vmcnt(1)/vmcnt(0) in front of the first MFMAs of the CURRENT
             // tile, i.e. every 64-key tile waited for the NEXT tile's HBM round trip: ~3.5k cycles per 32-key
-            // sub-tile instead of ~1k.)
+            // sub-tile instead of ~1k.)  A thread without a chunk (ROWS * CPR < 256) reads past the range: zeros, never stored.
             typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
             const int64_t span = ((int64_t)(row_end - 1) * gstride + D) * (int64_t)sizeof(T);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)span, 0x00020000);
-            static_assert(64 * CPR == 256 * NC, "whole chunks per thread");
 #pragma unroll
             for (int i = 0; i < NC; i++) {
                 const int c = tid + 256 * i;
                 const int row = c / CPR, cc = c % CPR;
-                const int off = (int)(((int64_t)(row0 + row) * gstride + cc * VN) * (int64_t)sizeof(T));
+                int off = (int)(((int64_t)(row0 + row) * gstride + cc * VN) * (int64_t)sizeof(T));
+                if (!WHOLE && c >= ROWS * CPR) off = 0x7FFFFFF0;
                 const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
                 r[i].v = __builtin_bit_cast(decltype(r[i].v), w);
             }
@@ -143,7 +148,7 @@ template <typename T, int D> struct Stager {
             const int row = c / CPR, cc = c % CPR;
 #pragma unroll
             for (int j = 0; j < VN; j++) r[i].set(j, 0.f);
-            if (c < 64 * CPR && row0 + row < row_end && cc * VN < D) r[i] = ld16(g + (int64_t)(row0 + row) * gstride + cc * VN);
+            if (c < ROWS * CPR && row0 + row < row_end && cc * VN < D) r[i] = ld16(g + (int64_t)(row0 + row) * gstride + cc * VN);
         }
     }
     __device__ __forceinline__ void store(T* img, int tid) const {
@@ -154,9 +159,9 @@ template <typename T, int D> struct Stager {
             // whole chunks per thread (every D >= 32): unconditional, so the stores are straight-line code that can be scheduled
             // among the tile's last MFMAs instead of four exec-masked blocks behind them
 #ifdef ATTN_COND_STORE
-            if (c < 64 * CPR) {
+            if (c < ROWS * CPR) {
 #else
-            if ((64 * CPR) % 256 == 0 || c < 64 * CPR) {
+            if (WHOLE || c < ROWS * CPR) {
 #endif
                 if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
@@ -456,21 +461,34 @@ __device__ __forceinline__ void attn_job(int plan_u, int nb, int H, int& by, int
 // =================================================================================================
 // AMASK: Transformer.call's attention_mask (transformer.py:774-779, 356-358): amask[b][key] = (1 - mask) * -1e4 is ADDED to the
 // scaled, causally masked scores of every query of batch row b (forward passes only; the train loop never passes a mask).
-template <typename T, int D, bool DROP, bool AMASK = false>
-__global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+// KS ("key split", small grids -- attn_key_split below): the workgroup owns ONE 32-row query block, its four waves take the four
+// 64-key quarters of every staged 256-key tile and their (m, l, O) partials are merged through LDS at the end: a quarter of the
+// serial tile walk per wave and four times the workgroups.  grid (ceil(T/32), B*H), heaviest block first.
+template <typename T, int D, bool DROP, bool AMASK = false, bool KS = false>
+__global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
                                                                           float* __restrict__ lse, int Tn, int H,
                                                                           float scale, DropCfg drop, int plan_u,
                                                                           const float* __restrict__ amask) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Kb = reinterpret_cast<T*>(smem_raw);          // 2 x { K [64][S] | V [64][S] }
-    constexpr int IMG = 64 * G::S;
+    T* Kb = reinterpret_cast<T*>(smem_raw);          // 2 x { K [KT][S] | V [KT][S] }
+    static_assert(!KS || (!EXACT && !AMASK), "key split: throughput mode without a mask term");
+    constexpr int KT = KS ? 256 : 64;                // keys per staged tile
+    constexpr int QR = KS ? 32 : 128;                // query rows per workgroup
+    constexpr int IMG = KT * G::S;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = KS ? wave * 64 : 0;               // this wave's keys inside a staged tile
     const int nb = cdiv(Tn, 128);
     int by, qb0, qb1;
-    attn_job(plan_u, nb, H, by, qb0, qb1);
+    if constexpr (KS) {
+        by = blockIdx.y;
+        qb0 = (int)gridDim.x - 1 - (int)blockIdx.x;
+        qb1 = -1;
+    } else {
+        attn_job(plan_u, nb, H, by, qb0, qb1);
+    }
 #if ATTN_DIAG == 9                                   // measurement build: every batch row aliases row 0 or 1 (data set stays in L2 / MALL)
     const int b = (by / H) & 1, hd = by % H;
 #else
@@ -505,7 +523,7 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
         const int qb = ph == 0 ? qb0 : qb1;
 #endif
         if (qb < 0) break;
-        const int q0w = qb * 128 + wave * 32;
+        const int q0w = KS ? qb * 32 : qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
         const bool qvalid = q < Tn;
         frag_t<T> qf[G::NS];
@@ -519,10 +537,10 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
         // With a mask term no key tile is skipped: a causally masked key sits at -1e4 + its mask term, and in a row whose allowed
         // keys are all masked out (a padding query) that is not negligible against the row maximum -- the reference's softmax
         // runs over all of them (transformer.py:351-360).
-        const int kv_end = AMASK ? Tn : min(Tn, qb * 128 + 128);
+        const int kv_end = AMASK ? Tn : min(Tn, qb * QR + QR);
         const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
 
-        Stager<T, D> sk, sv;
+        Stager<T, D, KT> sk, sv;
         sk.load(kg, rs, 0, Tn, tid);
         sv.load(vg, rs, 0, Tn, tid);
         sk.store(Kb, tid);
@@ -532,19 +550,20 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
         // that instance has no branch around an accumulating MFMA.  (With the skip/mask branches of the general form in
         // the only loop, hipcc carried the O^T accumulators through 64 v_mov_b64 per pair of tiles -- MFMA into a copy,
         // copy back at the join -- and waited out the MFMA pipeline before the copies.)
-        auto tile = [&](auto interior, const int kt0, const int it) __attribute__((always_inline)) {
-            const T* Ks = Kb + (it & 1) * 2 * IMG;
+        auto tile = [&](auto interior, const int kts, const int it) __attribute__((always_inline)) {
+            const T* Ks = Kb + (it & 1) * 2 * IMG + wk * G::S;
             const T* Vs = Ks + IMG;
-            const bool more = kt0 + 64 < kv_end;
+            const bool more = kts + KT < kv_end;
+            const int kt0 = kts + wk;                 // first key of this wave's 64
 #if ATTN_DIAG == 7          // every tile load re-reads tile 0 (L1 / L2 hits): instruction issue without the traffic
             if (more) {
-                sk.load(kg, rs, decltype(interior)::value ? 0 : kt0 + 64, Tn, tid);
-                sv.load(vg, rs, decltype(interior)::value ? 0 : kt0 + 64, Tn, tid);
+                sk.load(kg, rs, decltype(interior)::value ? 0 : kts + KT, Tn, tid);
+                sv.load(vg, rs, decltype(interior)::value ? 0 : kts + KT, Tn, tid);
             }
 #elif ATTN_DIAG != 5
             if (more) {
-                sk.load(kg, rs, kt0 + 64, Tn, tid);
-                sv.load(vg, rs, kt0 + 64, Tn, tid);
+                sk.load(kg, rs, kts + KT, Tn, tid);
+                sv.load(vg, rs, kts + KT, Tn, tid);
             }
 #endif
             // Fast path (throughput mode): all 64 keys of the tile are at or below every query of this wave -> no
@@ -700,10 +719,46 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q)) void attn_fwd_kernel(cons
 #endif
         };
         int kt0 = 0, it = 0;
-        const int interior_end = EXACT ? 0 : qb * 128;                 // keys below every query row of the block
-        for (; kt0 < interior_end; kt0 += 64, it++) tile(std::true_type{}, kt0, it);
-        for (; kt0 < kv_end; kt0 += 64, it++) tile(std::false_type{}, kt0, it);
-        const float ltot = half_sum(lsum);
+        const int interior_end = EXACT ? 0 : (qb * QR) / KT * KT;      // whole tiles below every query row of the block
+        for (; kt0 < interior_end; kt0 += KT, it++) tile(std::true_type{}, kt0, it);
+        for (; kt0 < kv_end; kt0 += KT, it++) tile(std::false_type{}, kt0, it);
+        float ltot = half_sum(lsum);
+        if constexpr (KS) {
+            // merge the four waves' partial softmax states (the last tile's barrier has passed: the staging buffers are free)
+            constexpr int NV = 2 + 16 * G::DT;
+            float* mg = reinterpret_cast<float*>(smem_raw);
+            if (wave > 0) {
+                float* w = mg + (wave - 1) * NV * 64 + lane;
+                w[0] = m;
+                w[64] = ltot;
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) w[(2 + 16 * dt + r) * 64] = oacc[dt][r];
+            }
+            __syncthreads();
+            if (wave > 0) continue;               // (single phase: leaves the loop)
+            float mstar = m;
+#pragma unroll
+            for (int w = 0; w < 3; w++) mstar = fmaxf(mstar, mg[w * NV * 64 + lane]);
+            const float a0 = fast_exp2((m - mstar) * c2);      // wave 0 always holds key 0: m is finite
+            ltot *= a0;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc[dt][r] *= a0;
+#pragma unroll
+            for (int w = 0; w < 3; w++) {
+                const float* src = mg + w * NV * 64 + lane;
+                const float aw = fast_exp2((src[0] - mstar) * c2);     // a wave without keys left m = -inf: factor 0
+                ltot = fmaf(src[64], aw, ltot);
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) oacc[dt][r] = fmaf(src[(2 + 16 * dt + r) * 64], aw, oacc[dt][r]);
+            }
+            m = mstar;
+        }
         const float inv = (DROP ? drop.scale : 1.0f) / ltot;
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(og, E, q, qvalid, dt, oacc[dt], inv, h);
@@ -1411,24 +1466,32 @@ __global__ __launch_bounds__(256, A4_MINW) void attn_fwd32d_kernel(const bf16_t*
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
 // With dropout (keep-scale f = 1/(1-p)):  dS = f * P * (M*dP~ - delta/f)  -> the f goes to the output scale.
 // =================================================================================================
-template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q))
-void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
-                                                                         const T* __restrict__ d_o,
-                                                                         const float* __restrict__ lse,
-                                                                         float* __restrict__ delta, T* __restrict__ dqkv,
-                                                                         float* __restrict__ bias_grad, int Tn, int H, float scale,
-                                                                         DropCfg drop, int plan_u) {
+// KS: as in the forward -- one 32-row query block per workgroup, the waves split every staged 256-key tile, dQ partials summed in LDS.
+// (the body is shared by attn_dq_kernel and the small-grid backward launch attn_bwd_ks_kernel, which passes its block in ks_blk)
+template <typename T, int D, bool DROP, int KS>
+__device__ __forceinline__ void attn_dq_body(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+                                             const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dqkv,
+                                             float* __restrict__ bias_grad, int Tn, int H, float scale, DropCfg drop, int plan_u,
+                                             int ks_blk) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* Kb = reinterpret_cast<T*>(smem_raw);          // 2 x { K | V }
-    constexpr int IMG = 64 * G::S;
+    static_assert(!KS || !EXACT, "key split: throughput mode");
+    constexpr int KT = KS ? 256 : 64, QR = KS ? 32 : 128;
+    constexpr int IMG = KT * G::S;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = KS ? wave * 64 : 0;
     const int nb = cdiv(Tn, 128);
     int by, qb0, qb1;
-    attn_job(plan_u, nb, H, by, qb0, qb1);
+    if constexpr (KS) {
+        by = blockIdx.y;
+        qb0 = ks_blk;
+        qb1 = -1;
+    } else {
+        attn_job(plan_u, nb, H, by, qb0, qb1);
+    }
     const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
@@ -1450,7 +1513,7 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
         const int qb = ph == 0 ? qb0 : qb1;
 #endif
         if (qb < 0) break;
-        const int q0w = qb * 128 + wave * 32;
+        const int q0w = KS ? qb * 32 : qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
         const bool qvalid = q < Tn;
         frag_t<T> qf[G::NS], dof[G::NS];
@@ -1468,10 +1531,10 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
         for (int dt = 0; dt < G::DT; dt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) dq[dt][r] = 0.f;
-        const int kv_end = min(Tn, qb * 128 + 128);
+        const int kv_end = min(Tn, qb * QR + QR);
         const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
 
-        Stager<T, D> sk, sv;
+        Stager<T, D, KT> sk, sv;
         sk.load(kg, rs, 0, Tn, tid);
         sv.load(vg, rs, 0, Tn, tid);
         sk.store(Kb, tid);
@@ -1487,21 +1550,22 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
             }
         }
         dsum = half_sum(dsum);
-        if (qvalid && h == 0) delta[(int64_t)by * Tn + q] = dsum;
+        if (qvalid && h == 0 && (!KS || wave == 0)) delta[(int64_t)by * Tn + q] = dsum;
         const float del_q = (qvalid ? dsum : 0.f) / keep_scale;
         __syncthreads();
         // One 64-key tile.  `interior` (compile time) = every key of the tile lies at or below every query row of the block and
         // every row and key exists: that instance carries NO mask code.  (Round 3 had the mask in one loop under a wave-uniform
         // `if (edge)`: hipcc if-converted it -- 32 integer compares + 16 selects + ~17 scalar mask operations in the block of the
         // score MFMAs of EVERY sub-tile, a fifth of the kernel's vector instructions, needed on two tiles in eighteen.)
-        auto tile = [&](auto interior, const int kt0, const int it) __attribute__((always_inline)) {
+        auto tile = [&](auto interior, const int kts, const int it) __attribute__((always_inline)) {
             constexpr bool INT = decltype(interior)::value;
-            const T* Ks = Kb + (it & 1) * 2 * IMG;
+            const T* Ks = Kb + (it & 1) * 2 * IMG + wk * G::S;
             const T* Vs = Ks + IMG;
-            const bool more = kt0 + 64 < kv_end;
+            const bool more = kts + KT < kv_end;
+            const int kt0 = kts + wk;                 // first key of this wave's 64
             if (more) {
-                sk.load(kg, rs, kt0 + 64, Tn, tid);
-                sv.load(vg, rs, kt0 + 64, Tn, tid);
+                sk.load(kg, rs, kts + KT, Tn, tid);
+                sv.load(vg, rs, kts + KT, Tn, tid);
             }
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
@@ -1548,35 +1612,70 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
             __syncthreads();
         };
         int kt0 = 0, it = 0;
-        const int interior_end = (EXACT || qb * 128 + 128 > Tn) ? 0 : qb * 128;     // keys below every (existing) query row of the block
-        for (; kt0 < interior_end; kt0 += 64, it++) tile(std::true_type{}, kt0, it);
-        for (; kt0 < kv_end; kt0 += 64, it++) tile(std::false_type{}, kt0, it);
+        const int interior_end = (EXACT || qb * QR + QR > Tn) ? 0 : (qb * QR) / KT * KT;     // whole tiles below every (existing) query row of the block
+        for (; kt0 < interior_end; kt0 += KT, it++) tile(std::true_type{}, kt0, it);
+        for (; kt0 < kv_end; kt0 += KT, it++) tile(std::false_type{}, kt0, it);
+        if constexpr (KS) {
+            // sum of the four waves' partial dQ^T tiles (the last tile's barrier has passed: the staging buffers are free)
+            float* mg = reinterpret_cast<float*>(smem_raw);
+            if (wave > 0) {
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) mg[(((wave - 1) * G::DT + dt) * 16 + r) * 64 + lane] = dq[dt][r];
+            }
+            __syncthreads();
+            if (wave > 0) continue;               // (single phase: leaves the loop)
+#pragma unroll
+            for (int w = 0; w < 3; w++)
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) dq[dt][r] += mg[((w * G::DT + dt) * 16 + r) * 64 + lane];
+        }
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale * keep_scale, h);
         if (bias_grad) colsum_t_tiles<T, D>(bias_grad + hd * D, qvalid, dq, scale * keep_scale, h, lane);
     }
+}
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q))
+void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o, const float* __restrict__ lse,
+                    float* __restrict__ delta, T* __restrict__ dqkv, float* __restrict__ bias_grad, int Tn, int H, float scale,
+                    DropCfg drop, int plan_u) {
+    attn_dq_body<T, D, DROP, 0>(qkv, o, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, plan_u, 0);
 }
 
 // =================================================================================================
 // dK, dV.  grid ((nb+1)/2, B*H): wave w owns keys [kb*128 + 32w, +32); loops over the query tiles at or below the
 // diagonal.  Key block j needs nb-j query blocks -> paired (j, nb-1-j) like the forward.
 // =================================================================================================
-template <typename T, int D, bool DROP>
-__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
-                                                                          const float* __restrict__ lse,
-                                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                                          float* __restrict__ bias_grad, int Tn, int H, float scale,
-                                                                          DropCfg drop) {
+// KS (small grids): one 32-key block per workgroup (grid (ceil(T/32), B*H), key block 0 = the heaviest first), the four waves take
+// the four 64-query quarters of every staged 256-query tile, dK / dV partials summed in LDS.
+// KS == 2 takes delta[q] = rowsum(dO . O) from `o` itself (a 32- or 64-byte row per thread and staged tile) instead of from the dQ
+// kernel: the two roles of a small backward then run side by side in ONE launch (attn_bwd_ks_kernel).
+template <typename T, int D, bool DROP, int KS>
+__device__ __forceinline__ void attn_dkv_body(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
+                                              const float* __restrict__ delta, T* __restrict__ dqkv, float* __restrict__ bias_grad,
+                                              int Tn, int H, float scale, DropCfg drop, const T* __restrict__ o, int ks_blk) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* Qb = reinterpret_cast<T*>(smem_raw);          // 2 x { Q [64][S] | dO [64][S] }
-    constexpr int IMG = 64 * G::S;
-    float* Lb = reinterpret_cast<float*>(Qb + 4 * IMG);     // 2 x { lse [64] | delta/f [64] | dropout row hash [64] }
+    T* Qb = reinterpret_cast<T*>(smem_raw);          // 2 x { Q [QT][S] | dO [QT][S] }
+    static_assert(!KS || !EXACT, "key split: throughput mode");
+    constexpr int QT = KS ? 256 : 64;                // queries per staged tile
+    constexpr int IMG = QT * G::S;
+    float* Lb = reinterpret_cast<float*>(Qb + (KS ? 2 : 4) * IMG);     // 2 x { lse [QT] | delta/f [QT] | dropout row hash [QT] } (KS: 1 x)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = KS ? wave * 64 : 0;               // this wave's queries inside a staged tile
     int bx, by;
-    xcd_block(bx, by, H);
+    if constexpr (KS) {
+        bx = ks_blk;
+        by = blockIdx.y;
+    } else {
+        xcd_block(bx, by, H);
+    }
     const int b = by / H, hd = by % H;
     const int E = H * D;
     const int64_t rs = 3 * E;
@@ -1592,9 +1691,9 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
 
     for (int ph = 0; ph < 2; ph++) {
         // light/heavy are mirrored w.r.t. the forward: key block 0 is the heavy one
-        const int kb = ((int)gridDim.x == nb && nb > 1) ? (ph == 0 ? bx : -1) : (ph == 0 ? bx : (bx < nb - 1 - bx ? nb - 1 - bx : -1));
+        const int kb = (KS || ((int)gridDim.x == nb && nb > 1)) ? (ph == 0 ? bx : -1) : (ph == 0 ? bx : (bx < nb - 1 - bx ? nb - 1 - bx : -1));
         if (kb < 0) break;
-        const int k0w = kb * 128 + wave * 32;
+        const int k0w = KS ? kb * 32 : kb * 128 + wave * 32;
         const int key = k0w + (lane & 31);
         const bool kvalid = key < Tn;
         frag_t<T> kf[G::NS], vf[G::NS];
@@ -1608,8 +1707,11 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; r++) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
-        Stager<T, D> sq, so;
+        Stager<T, D, QT> sq, so;
         float st_l = 0.f, st_d = 0.f;
+        constexpr int ORW = KS == 2 ? D / AT<T>::VN : 1;
+        Vec16<T> st_o[ORW], st_g[ORW];           // KS == 2: the thread's O and dO row of the next tile (delta is their dot product)
+        const T* og_ks = KS == 2 ? o + (int64_t)b * Tn * E + hd * D : nullptr;
         // per-row scalars of tile qt (threads 0..63): raw loads only -- any arithmetic on the loaded value here would make
         // the compiler wait for it (and for the tile loads issued before it) ahead of the current tile's MFMAs; the
         // scale factors are applied in store_rows, after the tile's work.  Rows past Tn read a clamped (finite) row;
@@ -1617,18 +1719,33 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
         // Every wave issues them (same 256 bytes, L1 hits): with the loads under `if (tid < 64)` the wait-count pass
         // sized the waits in front of the MFMAs for the shorter path and made the other wave stall on a tile load.
         auto load_rows = [&](int qt) {
-            const int qq = min(qt + (tid & 63), Tn - 1);
+            const int qq = min(qt + (tid & (QT - 1)), Tn - 1);
             st_l = lse[(int64_t)by * Tn + qq];
-            st_d = delta[(int64_t)by * Tn + qq];
-        };
-        auto store_rows = [&](float* dst, int qt) {
-            if (tid < 64) {
-                dst[tid] = st_l * (EXACT ? 1.0f : LOG2E_F);
-                dst[64 + tid] = st_d / keep_scale;
-                reinterpret_cast<uint32_t*>(dst)[128 + tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + qt + tid));
+            if constexpr (KS == 2) {
+#pragma unroll
+                for (int i = 0; i < ORW; i++) {
+                    st_o[i] = ld16(og_ks + (int64_t)qq * E + i * AT<T>::VN);
+                    st_g[i] = ld16(dog + (int64_t)qq * E + i * AT<T>::VN);
+                }
+            } else {
+                st_d = delta[(int64_t)by * Tn + qq];
             }
         };
-        const int qstart = kb * 128;
+        auto store_rows = [&](float* dst, int qt) {
+            if constexpr (KS == 2) {
+                st_d = 0.f;
+#pragma unroll
+                for (int i = 0; i < ORW; i++)
+#pragma unroll
+                    for (int j = 0; j < AT<T>::VN; j++) st_d = fmaf(st_o[i].get(j), st_g[i].get(j), st_d);
+            }
+            if (tid < QT) {
+                dst[tid] = st_l * (EXACT ? 1.0f : LOG2E_F);
+                dst[QT + tid] = st_d / keep_scale;
+                reinterpret_cast<uint32_t*>(dst)[2 * QT + tid] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + qt + tid));
+            }
+        };
+        const int qstart = KS ? (kb * 32) / 64 * 64 : kb * 128;
         sq.load(qg, rs, qstart, Tn, tid);
         so.load(dog, E, qstart, Tn, tid);
         load_rows(qstart);
@@ -1639,16 +1756,20 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
         // One 64-query tile.  `interior` (compile time) = every query row of the tile lies below every key of the block and every
         // row and key exists: no mask code in that instance (see the dQ kernel: the if-converted mask was a fifth of the vector
         // instructions of every sub-tile).
-        auto tile = [&](auto interior, const int qt0, const int it) __attribute__((always_inline)) {
+        auto tile = [&](auto interior, const int qts, const int it) __attribute__((always_inline)) {
             constexpr bool INT = decltype(interior)::value;
-            const T* Qs = Qb + (it & 1) * 2 * IMG;
+            // KS stages into ONE buffer (a barrier in front of the refill): 43 KiB of LDS at D = 16, three workgroups per CU -- the
+            // double-buffered 86 KiB left one per CU and the 512 workgroups of the default configuration took two rounds
+            const int sb = KS ? 0 : (it & 1);
+            const T* Qs = Qb + sb * 2 * IMG + wq * G::S;
             const T* Os = Qs + IMG;
-            const float* Ls = Lb + (it & 1) * 192;
-            const bool more = qt0 + 64 < Tn;
+            const float* Ls = Lb + sb * 3 * QT + wq;
+            const bool more = qts + QT < Tn;
+            const int qt0 = qts + wq;                 // first query of this wave's 64
             if (more) {
-                sq.load(qg, rs, qt0 + 64, Tn, tid);
-                so.load(dog, E, qt0 + 64, Tn, tid);
-                load_rows(qt0 + 64);
+                sq.load(qg, rs, qts + QT, Tn, tid);
+                so.load(dog, E, qts + QT, Tn, tid);
+                load_rows(qts + QT);
             }
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
@@ -1666,8 +1787,8 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
                 for (int g = 0; g < 4; g++) {
                     const int ql = 32 * sub + 8 * g + 4 * h;
                     lq[g] = *reinterpret_cast<const f32x4*>(Ls + ql);
-                    dq4[g] = *reinterpret_cast<const f32x4*>(Ls + 64 + ql);
-                    if constexpr (DROP) rh4[g] = *reinterpret_cast<const __attribute__((ext_vector_type(4))) uint32_t*>(Ls + 128 + ql);
+                    dq4[g] = *reinterpret_cast<const f32x4*>(Ls + QT + ql);
+                    if constexpr (DROP) rh4[g] = *reinterpret_cast<const __attribute__((ext_vector_type(4))) uint32_t*>(Ls + 2 * QT + ql);
                 }
                 f32x16 pt;
 #pragma unroll
@@ -1714,19 +1835,44 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
                 }
             }
             if (more) {
-                T* nbuf = Qb + ((it & 1) ^ 1) * 2 * IMG;
+                if constexpr (KS) __syncthreads();
+                T* nbuf = Qb + (KS ? 0 : (sb ^ 1)) * 2 * IMG;
                 sq.store(nbuf, tid);
                 so.store(nbuf + IMG, tid);
-                store_rows(Lb + ((it & 1) ^ 1) * 192, qt0 + 64);
+                store_rows(Lb + (KS ? 0 : (sb ^ 1)) * 3 * QT, qts + QT);
             }
             __syncthreads();
         };
         // the diagonal block's tiles (masked), then the tiles below it (interior), then a ragged last tile (masked)
         int qt0 = qstart, it = 0;
-        const int diag_end = EXACT ? Tn : min(Tn, qstart + 128);
-        for (; qt0 < diag_end; qt0 += 64, it++) tile(std::false_type{}, qt0, it);
-        for (; qt0 + 64 <= Tn; qt0 += 64, it++) tile(std::true_type{}, qt0, it);
-        for (; qt0 < Tn; qt0 += 64, it++) tile(std::false_type{}, qt0, it);
+        const int diag_end = EXACT ? Tn : min(Tn, KS ? k0w + 32 : qstart + 128);
+        for (; qt0 < diag_end; qt0 += QT, it++) tile(std::false_type{}, qt0, it);
+        for (; qt0 + QT <= Tn; qt0 += QT, it++) tile(std::true_type{}, qt0, it);
+        for (; qt0 < Tn; qt0 += QT, it++) tile(std::false_type{}, qt0, it);
+        if constexpr (KS) {
+            // sum of the four waves' partial dK^T / dV^T tiles (the last tile's barrier has passed: the staging buffers are free)
+            float* mg = reinterpret_cast<float*>(smem_raw);
+            if (wave > 0) {
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        mg[(((wave - 1) * 2 * G::DT + 2 * dt) * 16 + r) * 64 + lane] = dk[dt][r];
+                        mg[(((wave - 1) * 2 * G::DT + 2 * dt + 1) * 16 + r) * 64 + lane] = dv[dt][r];
+                    }
+            }
+            __syncthreads();
+            if (wave > 0) continue;               // (single phase: leaves the loop)
+#pragma unroll
+            for (int w = 0; w < 3; w++)
+#pragma unroll
+                for (int dt = 0; dt < G::DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        dk[dt][r] += mg[((w * 2 * G::DT + 2 * dt) * 16 + r) * 64 + lane];
+                        dv[dt][r] += mg[((w * 2 * G::DT + 2 * dt + 1) * 16 + r) * 64 + lane];
+                    }
+        }
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) {
             store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale * keep_scale, h);
@@ -1737,6 +1883,39 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
             colsum_t_tiles<T, D>(bias_grad + 2 * E + hd * D, kvalid, dv, keep_scale, h, lane);
         }
     }
+}
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                                          const float* __restrict__ lse,
+                                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                                          float* __restrict__ bias_grad, int Tn, int H, float scale,
+                                                                          DropCfg drop) {
+    attn_dkv_body<T, D, DROP, 0>(qkv, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, nullptr, 0);
+}
+// The whole backward of a small grid in one launch: grid (2 * ceil(T/32), B*H); even x = dK/dV of key block x/2, odd x = dQ of query
+// block ceil(T/32) - 1 - x/2 -- the heaviest blocks of both roles first, the lightest last, so the second round of workgroups (two
+// fit a CU) fills the slots the light ones leave.  (Side by side on two streams the pair lost to its event fork / join, NEGATIVE_RESULTS.)
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_ks_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+                                                             const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dqkv,
+                                                             float* __restrict__ bias_grad, int Tn, int H, float scale, DropCfg drop) {
+    const int x = blockIdx.x, nqb = (int)gridDim.x >> 1;
+    if (x & 1) attn_dq_body<T, D, DROP, 1>(qkv, o, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, -1, nqb - 1 - (x >> 1));
+    else attn_dkv_body<T, D, DROP, 2>(qkv, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, o, x >> 1);
+}
+// ... and as two launches where the merged grid would not be resident at once (the default configuration at T = 1024: 1024 workgroups on
+// 512 slots took 59 us merged against 19 + 29 us apart); dK/dV then reads the delta the dQ launch stored.
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_dq_ks_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+                                                            const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dqkv,
+                                                            float* __restrict__ bias_grad, int Tn, int H, float scale, DropCfg drop) {
+    attn_dq_body<T, D, DROP, 1>(qkv, o, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, -1, (int)gridDim.x - 1 - (int)blockIdx.x);
+}
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_dkv_ks_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, T* __restrict__ dqkv, float* __restrict__ bias_grad,
+                                                             int Tn, int H, float scale, DropCfg drop) {
+    attn_dkv_body<T, D, DROP, 1>(qkv, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, nullptr, (int)blockIdx.x);
 }
 
 // =================================================================================================
@@ -1770,6 +1949,16 @@ static dim3 attn_plan_grid(int Tn, int BH, int u) {
     if (u < 0) return dim3(attn_grid_x(Tn, BH), BH);
     const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2, rows_x = BH / 8;
     return dim3(8 * ((rows_x - u) * pairs + u * nb), 1);
+}
+// Small grids (the reference's default configuration at batch 1: 16 (batch, head) rows of 1024 tokens = 128 workgroups of the
+// 128-row kind, every one a serial walk over up to 16 key tiles at ~1 us each): the key-split forms of the three kernels (KS).
+// COMPOSER_ATTN_KS=0 turns them off, =1 forces them wherever they exist (tests).
+static bool attn_key_split(int Tn, int BH, int D, bool bf16) {
+    if (!bf16 || D > 32 || Tn < 64) return false;       // (at D = 64 the 256-row staging registers spill: not built)
+    static const int mode = [] { const char* e = getenv("COMPOSER_ATTN_KS"); return e ? atoi(e) : -1; }();
+    if (mode == 0) return false;
+    if (mode == 1) return true;
+    return (int64_t)cdiv(Tn, 128) * BH <= 256;
 }
 template <typename K> static int attn_wgs_per_cu(K kernel, size_t smem) {
     int n = 0;
@@ -1849,6 +2038,24 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
         }
     }
 #endif
+    if constexpr (std::is_same<T, bf16_t>::value && D <= 32) {
+        if (!amask && attn_key_split(Tn, B * H, D, true)) {
+            const size_t smem_ks = 4 * 256 * Geo<T, D>::S * sizeof(T);
+            static const bool attr_ks = [&] {
+                bool ok = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                return ok;
+            }();
+            CMP_REQUIRE(attr_ks, "attention: the key-split forward kernel does not get %zu bytes of LDS", smem_ks);
+            const dim3 grid(cdiv(Tn, 32), B * H);
+            PROF_START(3, s);
+            if (d.thr) attn_fwd_kernel<T, D, true, false, true><<<grid, 256, smem_ks, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, -1, nullptr);
+            else attn_fwd_kernel<T, D, false, false, true><<<grid, 256, smem_ks, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, -1, nullptr);
+            PROF_STOP(3, s, 2.0 * B * H * (double)Tn * Tn * D, (double)B * Tn * H * (4.0 * D * sizeof(T) + 4.0));
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+    }
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem > 65536) {
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1878,6 +2085,45 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
 template <typename T, int D>
 static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                       void* dqkv, int B, int Tn, int H, float scale, DropCfg d, float* bias_grad) {
+    if constexpr (std::is_same<T, bf16_t>::value && D <= 32) {
+        if (attn_key_split(Tn, B * H, D, true)) {
+            // one launch, both roles: LDS = the larger of the two (dQ double-buffers its 256-key tiles)
+            const size_t smem_ks = 4 * 256 * Geo<T, D>::S * sizeof(T);
+            const size_t smem_kv = smem_ks / 2 + 3 * 256 * sizeof(float);
+            static const bool attr_ks = [&] {
+                bool ok = hipFuncSetAttribute((const void*)attn_bwd_ks_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_bwd_ks_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dq_ks_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dq_ks_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dkv_ks_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dkv_ks_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv) == hipSuccess;
+                return ok;
+            }();
+            CMP_REQUIRE(attr_ks, "attention: the key-split backward kernels do not get %zu bytes of LDS", smem_ks);
+            const double flk = (double)B * H * (double)Tn * Tn * D;
+            if ((int64_t)2 * cdiv(Tn, 32) * B * H > 512) {         // not resident at once: two launches
+                const dim3 g1(cdiv(Tn, 32), B * H);
+                PROF_START(4, s);
+                if (d.thr) attn_dq_ks_kernel<T, D, true><<<g1, 256, smem_ks, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+                else attn_dq_ks_kernel<T, D, false><<<g1, 256, smem_ks, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+                PROF_STOP(4, s, 3.0 * flk, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));
+                KERNEL_CHECK();
+                PROF_START(5, s);
+                if (d.thr) attn_dkv_ks_kernel<T, D, true><<<g1, 256, smem_kv, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+                else attn_dkv_ks_kernel<T, D, false><<<g1, 256, smem_kv, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+                PROF_STOP(5, s, 4.0 * flk, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));
+                KERNEL_CHECK();
+                return CMP_OK;
+            }
+            const dim3 kgrid(2 * cdiv(Tn, 32), B * H);
+            PROF_START(5, s);                  // (counted with the dK/dV class: one launch carries the seven products)
+            if (d.thr) attn_bwd_ks_kernel<T, D, true><<<kgrid, 256, smem_ks, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+            else attn_bwd_ks_kernel<T, D, false><<<kgrid, 256, smem_ks, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
+            PROF_STOP(5, s, 7.0 * flk, (double)B * Tn * H * (9.0 * D * sizeof(T) + 8.0));
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+    }
     dim3 grid(attn_grid_x(Tn, B * H), B * H);
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem + 1536 > 65536) {

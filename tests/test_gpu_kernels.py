@@ -216,11 +216,13 @@ def test_gemm_epilogues(lib, dtype, flags):
 
 
 @pytest.mark.parametrize("tb", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (768, 1024, 96), (1024, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (768, 1024, 96), (1024, 512, 512), (1024, 256, 1024), (1024, 256, 768)])
 def test_gemm_epilogue_kinds_full_tiles(lib, tb, M, N, K):
     """Full 256x256 tiles with bf16 output take the compile-time epilogue kinds (gemm.hip EPI_*: operand loads two
     chunks ahead, counted waits) on the forward (tb=0, deep pipeline) and dgrad (tb=1, 2-stage 256) kernels.  Each kind
-    must agree with the fp64 reference and, element by element, with the run-time epilogue of the 128x128 kernel (flags=4)."""
+    must agree with the fp64 reference and, element by element, with the run-time epilogue of the 128x128 kernel (flags=4).
+    The last three shapes are launches of few 128x128 tiles with a long K (the default configuration's c_proj / dgrad GEMMs at 1 024
+    tokens), which stay on the 128x128 kernel and its compile-time kinds."""
     g = torch.Generator().manual_seed(M + N + K + tb)
     a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) * 0.2
     A, B = dev(a, BF16), dev(b.t().contiguous() if tb else b, BF16)
@@ -264,7 +266,7 @@ def test_gemm_epilogue_kinds_full_tiles(lib, tb, M, N, K):
     assert rel_err(out, acc.cpu() * torch.tensor(O.gelu_grad(pre.double().cpu().numpy()))) < TOL[BF16]
 
 
-@pytest.mark.parametrize("M,N,K,tb", [(512, 512, 256, 1), (1024, 768, 128, 0), (136, 264, 128, 1)])
+@pytest.mark.parametrize("M,N,K,tb", [(512, 512, 256, 1), (1024, 768, 128, 0), (136, 264, 128, 1), (1024, 256, 1024, 1)])
 def test_gemm_fused_column_sums(lib, M, N, K, tb):
     """cmp_gemm_colsum_next: the next GEMM also accumulates the column sums of its STORED bf16 output into an fp32
     vector (bias gradient) -- fused into the compile-time epilogues (full 256-tiles) or via a colsum pass (ragged)."""
@@ -466,6 +468,20 @@ def test_attention_block_plans(lib, dtype, B, H, D, T, p):
     rows = B * H
     groups = sorted({(0, 0), (0, H - 1), ((rows // 2) // H, (rows // 2) % H), ((rows - 9) // H, (rows - 9) % H), (B - 1, H - 1)})
     check_attention_groups(lib, B, H, D, T, dtype, p, groups)
+
+
+@pytest.mark.parametrize("B,H,D,T,p", [
+    (1, 16, 16, 1024, 0.1),      # the reference's default configuration (default_config.yml:32-48) at batch 1
+    (1, 16, 16, 1000, 0.0),      # ragged: the last 256-row staging tile and the last 32-row block are partial
+    (2, 4, 32, 600, 0.1),        # head size 32; three staging tiles, the last one ragged
+    (1, 2, 16, 96, 0.1),         # a single staging tile: three of the four waves own no key at all for the first block
+])
+def test_attention_key_split_kernels(lib, B, H, D, T, p):
+    """Small grids (B*H*ceil(T/128) <= 256 workgroups of the 128-row kind, bf16, head size <= 32) run the key-split forms of the
+    three attention kernels (attention.hip KS): 32-row blocks, the four waves of a workgroup split every staged 256-row tile and
+    merge their partial softmax states / gradient tiles through LDS.  Every (batch, head) group against float64, with the
+    dropout masks the other kernels draw."""
+    check_attention_groups(lib, B, H, D, T, BF16, p, [(b, h) for b in range(B) for h in range(H)][:6] + [(B - 1, H - 1)])
 
 
 def test_attention_forced_rescale(lib):
