@@ -1958,7 +1958,9 @@ static bool attn_key_split(int Tn, int BH, int D, bool bf16) {
     static const int mode = [] { const char* e = getenv("COMPOSER_ATTN_KS"); return e ? atoi(e) : -1; }();
     if (mode == 0) return false;
     if (mode == 1) return true;
-    return (int64_t)cdiv(Tn, 128) * BH <= 256;
+    // one round of 512 key-split workgroups (two per CU); with twice the rows the split already loses (default model at batch 2:
+    // 2.17 vs 2.01 ms/step, tools/ks_threshold_probe.py)
+    return (int64_t)cdiv(Tn, 128) * BH <= 128;
 }
 template <typename K> static int attn_wgs_per_cu(K kernel, size_t smem) {
     int n = 0;

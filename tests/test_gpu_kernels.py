@@ -477,7 +477,7 @@ def test_attention_block_plans(lib, dtype, B, H, D, T, p):
     (1, 2, 16, 96, 0.1),         # a single staging tile: three of the four waves own no key at all for the first block
 ])
 def test_attention_key_split_kernels(lib, B, H, D, T, p):
-    """Small grids (B*H*ceil(T/128) <= 256 workgroups of the 128-row kind, bf16, head size <= 32) run the key-split forms of the
+    """Small grids (B*H*ceil(T/128) <= 128 workgroups of the 128-row kind, bf16, head size <= 32) run the key-split forms of the
     three attention kernels (attention.hip KS): 32-row blocks, the four waves of a workgroup split every staged 256-row tile and
     merge their partial softmax states / gradient tiles through LDS.  Every (batch, head) group against float64, with the
     dropout masks the other kernels draw."""
