@@ -842,7 +842,12 @@ static int epi_kind_of(const Epilogue& ep, int M, int N, bool swap, bool slabs, 
     return ep.drop.thr ? EPI_GENERIC : EPI_PLAIN;
 }
 
-template <bool A_KM, bool B_KM, bool SWAP, int EPI = EPI_GENERIC>
+// RING (launches of at most one workgroup per CU -- the reference's default configuration runs GEMMs of 16-64 tiles on 256 CUs): a ring of
+// four k-stages, three in flight, LDS-DMA issued from inline asm behind hand-counted s_waitcnt vmcnt.  The two-stage loop below drains
+// every stage at its barrier (hipcc's wait-count pass sees the pending LDS write of the builtin and puts vmcnt(0) in front of the next
+// fragment read), so a k-step of such a launch costs one operand round trip, 0.5 us from a warm L2 and ~1 us in the model, where the
+// A operand was written by the previous kernel; with 128 KiB of stages in flight the round trips overlap.
+template <bool A_KM, bool B_KM, bool SWAP, int EPI = EPI_GENERIC, bool RING = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
                                                                 Epilogue ep, int ktiles_per_split, int tiles_n, int ntiles) {
@@ -876,6 +881,56 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (RING) {
+        static_assert(A_KM && B_KM, "ring: both operands K-contiguous");
+        constexpr int NST = 4;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
+        const v4i32 sa = make_srd(abase, a_bytes), sb = make_srd(bbase, b_bytes);
+        auto issue = [&](int kt, int slot) {              // this wave's 4 + 4 one-KiB pieces of stage kt (the layout of glds_tile<true>)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int p = wave * 4 + i, r = 8 * p + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+                dma16(sa, lds0 + slot * 2 * G_IMG + p * 1024, r * lda * 2 + (kt * G_BK + c * 8) * 2);
+                dma16(sb, lds0 + slot * 2 * G_IMG + G_IMG + p * 1024, r * ldb * 2 + (kt * G_BK + c * 8) * 2);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < NST - 1; i++)
+            if (kt0 + i < kt1) issue(kt0 + i, i);
+        for (int kt = kt0; kt < kt1; kt++) {
+            const int rel = kt - kt0, slot = rel & (NST - 1);
+            // stage kt has landed once at most the (up to two) younger stages of this wave are outstanding, eight pieces each; the
+            // barrier then vouches for the other waves' pieces -- and for their having finished with the slot that is refilled next
+            const int younger = min(NST - 2, kt1 - 1 - kt);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NST - 1 < kt1) issue(kt + NST - 1, (rel + NST - 1) & (NST - 1));
+            const char* ia = smem + slot * 2 * G_IMG;
+            const char* ib = ia + G_IMG;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    fa[i] = g_frag<A_KM>(ia, wm * 4 + i, ks, lane);
+                    fb[i] = g_frag<B_KM>(ib, wn * 4 + i, ks, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // the epilogue's staging areas lie over slot 0
+        asm volatile("" ::: "memory");
+    } else {
     if (kt0 < kt1) {
         glds_tile<A_KM>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
         glds_tile<B_KM>(rb, smem + G_IMG, ldb * 2, kt0 * G_BK, wave, lane);
@@ -907,6 +962,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(int M, int N, in
                 }
         }
         __syncthreads();     // also drains the LDS-DMA of the next tile (vmcnt(0) is emitted with the barrier)
+    }
     }
     if (SWAP) {
         // Epilogue through LDS (the pipeline buffers are free after the loop's last barrier): each wave parks its
@@ -2033,6 +2089,27 @@ static bool launch_fast(hipStream_t s, dim3 grid, size_t smem, bool swap, int M,
         static const bool kinds_on = [] { const char* e = getenv("COMPOSER_GEMM_FAST_KINDS"); return !(e && e[0] == '0'); }();
         const int kind = (kinds_on && grid.y == 1) ? epi_kind_of(ep, M, N, swap, false, 128) : EPI_GENERIC;
         auto go = [&](auto kern) { kern<<<grid, 256, smem, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles); };
+        // at most one workgroup per CU and whole k-steps: the four-stage ring (COMPOSER_GEMM_RING=0 off, =<n> from n k-steps on)
+        static const int ring_min = [] { const char* e = getenv("COMPOSER_GEMM_RING"); return e ? atoi(e) : 2; }();       // fewest k-steps that take it
+        if (kind != EPI_GENERIC && ring_min > 0 && ntiles <= 256 && K % G_BK == 0 && K >= std::max(2, ring_min) * G_BK) {
+            constexpr int smem_ring = 4 * 2 * G_IMG;
+            static const bool attr = [] {
+                bool ok = true;
+                auto set = [&](auto kern) { ok = ok && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_ring) == hipSuccess; };
+                set(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_PLAIN, true>);
+                set(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_RESID, true>);
+                set(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_GELUGRAD, true>);
+                set(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_GELU_AUX, true>);
+                return ok;
+            }();
+            if (attr) {
+                auto gor = [&](auto kern) { kern<<<grid, 256, smem_ring, s>>>(M, N, K, a, lda, b, ldb, C, ldc, ep, per, tiles_n, ntiles); };
+                if (kind == EPI_PLAIN) { gor(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_PLAIN, true>); return true; }
+                if (kind == EPI_RESID) { gor(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_RESID, true>); return true; }
+                if (kind == EPI_GELUGRAD) { gor(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_GELUGRAD, true>); return true; }
+                if (kind == EPI_GELU_AUX) { gor(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_GELU_AUX, true>); return true; }
+            }
+        }
         if (kind == EPI_PLAIN) { go(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_PLAIN>); return true; }
         if (kind == EPI_RESID) { go(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_RESID>); return true; }
         if (kind == EPI_GELUGRAD) { go(gemm_bf16_fast_kernel<A_KM, B_KM, true, EPI_GELUGRAD>); return true; }

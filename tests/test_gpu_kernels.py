@@ -216,13 +216,15 @@ def test_gemm_epilogues(lib, dtype, flags):
 
 
 @pytest.mark.parametrize("tb", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (768, 1024, 96), (1024, 512, 512), (1024, 256, 1024), (1024, 256, 768)])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (768, 1024, 96), (1024, 512, 512), (1024, 256, 1024), (1024, 256, 768),
+                                   (256, 256, 128), (256, 384, 192), (384, 256, 320), (128, 128, 576)])
 def test_gemm_epilogue_kinds_full_tiles(lib, tb, M, N, K):
     """Full 256x256 tiles with bf16 output take the compile-time epilogue kinds (gemm.hip EPI_*: operand loads two
     chunks ahead, counted waits) on the forward (tb=0, deep pipeline) and dgrad (tb=1, 2-stage 256) kernels.  Each kind
     must agree with the fp64 reference and, element by element, with the run-time epilogue of the 128x128 kernel (flags=4).
-    The last three shapes are launches of few 128x128 tiles with a long K (the default configuration's c_proj / dgrad GEMMs at 1 024
-    tokens), which stay on the 128x128 kernel and its compile-time kinds."""
+    Shapes of at most 256 128x128 tiles with whole 64-deep k-steps and both operands K-contiguous (tb=1: the default configuration's
+    GEMMs at 1 024 tokens) run the four-stage ring of the 128x128 kernel: 2, 3, 4, 5, 8, 9, 12 and 16 k-steps here (prologue shorter
+    than the ring, slot wrap-around, a last stage in slot 0 under the epilogue's staging areas)."""
     g = torch.Generator().manual_seed(M + N + K + tb)
     a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) * 0.2
     A, B = dev(a, BF16), dev(b.t().contiguous() if tb else b, BF16)
