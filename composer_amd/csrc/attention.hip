@@ -1921,6 +1921,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_ks_kernel(const T* __restrict
 // =================================================================================================
 // host launchers
 // =================================================================================================
+int colsum_run(void* stream, const void* X, int ldx, float* out, int rows, int cols, int dtype, float* det_ws, size_t det_ws_bytes);   // elementwise.hip
 // grid.x: block pairs, or single blocks when the paired grid would leave most of the 256 CUs x 2-3 workgroups without work
 static int attn_grid_x(int Tn, int BH) {
     const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2;
@@ -2103,6 +2104,15 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
             }();
             CMP_REQUIRE(attr_ks, "attention: the key-split backward kernels do not get %zu bytes of LDS", smem_ks);
             const double flk = (double)B * H * (double)Tn * Tn * D;
+            // The c_attn bias gradient (column sums of [dQ | dK | dV]) is NOT fused here: every workgroup of a head adds to the same 16
+            // addresses, and device-scope float atomics on one address retire ~0.5 us apart -- 16.5 of the 29.4 us of the dK/dV launch
+            // and ~4 of dQ's 19 at the default configuration (measurement builds, profiles/r5_06).  A column-sum pass over the
+            // [tokens, 3E] gradient costs ~5 us at these sizes (63 us at the benchmark's, where the fused sums stay).
+            float* const bias_out = bias_grad;
+            bias_grad = nullptr;
+            auto bias_pass = [&]() -> int {
+                return bias_out ? colsum_run(s, dqkv, 3 * H * D, bias_out, B * Tn, 3 * H * D, CMP_BF16, nullptr, 0) : CMP_OK;
+            };
             if ((int64_t)2 * cdiv(Tn, 32) * B * H > 512) {         // not resident at once: two launches
                 const dim3 g1(cdiv(Tn, 32), B * H);
                 PROF_START(4, s);
@@ -2115,7 +2125,7 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
                 else attn_dkv_ks_kernel<T, D, false><<<g1, 256, smem_kv, s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
                 PROF_STOP(5, s, 4.0 * flk, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));
                 KERNEL_CHECK();
-                return CMP_OK;
+                return bias_pass();
             }
             const dim3 kgrid(2 * cdiv(Tn, 32), B * H);
             PROF_START(5, s);                  // (counted with the dK/dV class: one launch carries the seven products)
@@ -2123,10 +2133,17 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
             else attn_bwd_ks_kernel<T, D, false><<<kgrid, 256, smem_ks, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
             PROF_STOP(5, s, 7.0 * flk, (double)B * Tn * H * (9.0 * D * sizeof(T) + 8.0));
             KERNEL_CHECK();
-            return CMP_OK;
+            return bias_pass();
         }
     }
     dim3 grid(attn_grid_x(Tn, B * H), B * H);
+    // Short launches take the c_attn bias sums out of the kernels too (see the key-split branch): the fused float atomics leave a ~16 us
+    // tail that only a launch of several rounds hides.  Same box, [tokens, 3E] gradient of 1.6 ... 12.6 MB (the default model at batch
+    // 1 ... 8): 2.99 -> 2.67 ms/step at batch 8, 1.95 -> 1.76 at batch 2; 25 MB (6L/8H/d512 at batch 8): 3.03 vs 3.04; 100 MB (batch 32):
+    // 7.39 vs 7.43 -- the pass re-reads the gradient, so it stops at 16 MiB (COMPOSER_ATTN_BIAS_PASS=<MiB> overrides, 0 = never).
+    static const int bias_pass_mib = [] { const char* e = getenv("COMPOSER_ATTN_BIAS_PASS"); return e ? atoi(e) : 16; }();
+    float* bias_out = nullptr;
+    if (bias_grad && std::is_same<T, bf16_t>::value && (int64_t)B * Tn * 3 * H * D * 2 <= (int64_t)bias_pass_mib << 20) { bias_out = bias_grad; bias_grad = nullptr; }
     size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
     if (smem + 1536 > 65536) {
         HIP_CHECK(hipFuncSetAttribute((const void*)attn_dq_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -2148,6 +2165,7 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
     else attn_dkv_kernel<T, D, false><<<grid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d);
     PROF_STOP(5, s, 4.0 * fl, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));       // q, k, v, dO, lse, delta in; dK, dV out
     KERNEL_CHECK();
+    if (bias_out) return colsum_run(s, dqkv, 3 * H * D, bias_out, B * Tn, 3 * H * D, CMP_BF16, nullptr, 0);
     return CMP_OK;
 }
 

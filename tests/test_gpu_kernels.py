@@ -486,6 +486,42 @@ def test_attention_key_split_kernels(lib, B, H, D, T, p):
     check_attention_groups(lib, B, H, D, T, BF16, p, [(b, h) for b in range(B) for h in range(H)][:6] + [(B - 1, H - 1)])
 
 
+@pytest.mark.parametrize("B,H,D,T,p,fused", [
+    (8, 8, 64, 1024, 0.1, True),       # [tokens, 3E] gradient of 25 MB: the sums stay fused in dQ / dK-dV (float atomics)
+    (5, 12, 64, 2048, 0.0, True),      # C4's head layout, 47 MB
+    (1, 16, 16, 1024, 0.1, False),     # 1.6 MB: key-split kernels, the sums come from a column-sum pass over the stored gradient
+    (8, 16, 16, 1024, 0.1, False),     # 12.6 MB: the 128-row kernels, column-sum pass
+])
+def test_attention_bias_gradient_paths(lib, B, H, D, T, p, fused):
+    """The c_attn bias gradient = column sums of [dQ | dK | dV] (Conv1D bias under tf.GradientTape, transformer.py:205-209): fused
+    into the backward kernels from their f32 accumulators where the launch is long enough to hide the atomics, a pass over the stored
+    bf16 gradient otherwise (attention.hip launch_bwd: 16 MiB).  Either way it must equal the column sums of the gradient the same
+    call stored -- exactly those of the stored values for the pass, within bf16 rounding of the summands for the fused form -- and
+    accumulate on top of the vector's contents."""
+    E = H * D
+    g = torch.Generator().manual_seed(B + T + D)
+    qkv = dev(torch.randn(B * T, 3 * E, generator=g), BF16)
+    do = dev(torch.randn(B * T, E, generator=g), BF16)
+    o = torch.zeros(B * T, E, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(B * H * T, device="cuda")
+    ck(lib, lib.cmp_k_attn_fwd(stream(), P(qkv), P(o), P(lse), B, T, H, D, 1, BF16, p, 5, 3))
+    dqkv = torch.zeros(B * T, 3 * E, device="cuda", dtype=torch.bfloat16)
+    delta = torch.zeros(B * H * T, device="cuda")
+    bias = torch.full((3 * E,), 7.0, device="cuda")
+    ck(lib, lib.cmp_attn_bwd_bias_next(P(bias)))
+    ck(lib, lib.cmp_k_attn_bwd(stream(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, BF16, p, 5, 3))
+    torch.cuda.synchronize()
+    assert (B * T * 3 * E * 2 > 16 << 20) == fused
+    want = dqkv.double().sum(0).cpu() + 7.0
+    scale = dqkv.double().abs().sum(0).cpu().clamp_min(1e-30)           # rounding of the summands is relative to their magnitudes
+    err = ((bias.double().cpu() - want).abs() / scale).max().item()
+    assert err < (3e-3 if fused else 2e-6), err
+    # not armed: the next call leaves the vector alone
+    ck(lib, lib.cmp_k_attn_bwd(stream(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, BF16, p, 5, 3))
+    torch.cuda.synchronize()
+    assert ((bias.double().cpu() - want).abs() / scale).max().item() == err
+
+
 def test_attention_forced_rescale(lib):
     """Online-softmax rescale branch: a key far down the sequence dominates a query row (rule: force the branch)."""
     B, T, H, D = 1, 192, 1, 64
