@@ -53,13 +53,17 @@ def check(c):
         l2, a2 = m.loss_and_grads(x, y)
         assert abs(l2 - loss) <= (3e-5 if not bf else 2e-2) * abs(loss), ("loss", l2, loss)
         worst = 0.0
+        # bf16: the floor also scales with the model's largest gradient (1e-3 of it) -- with a two-word vocabulary ln_f/beta cancels to
+        # ~2e-5 and carries the bf16 rounding residue of its summands (seed 79 of round 5: 1.3e-6 absolute = 6 % of that tensor's
+        # maximum, bit-identical on the round-4 library)
+        gfloor = 1e-5 + (1e-3 * max(np.abs(G[n]).max() for n in m.parameter_names) if bf else 0.0)
         for n in m.parameter_names:
             if not c["use_ln"] and ("ln_1" in n or "ln_2" in n):
                 continue
             gr = m.get_parameter(n, _lib.KIND_GRAD).astype(np.float64)
             # relative to the tensor's largest element, with a floor: a gradient that cancels to ~1e-7 (ln_f/beta with a two-word
             # vocabulary) carries fp32 rounding residue of the same size
-            worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + 1e-5))
+            worst = max(worst, np.abs(gr - G[n]).max() / (np.abs(G[n]).max() + gfloor))
         assert worst <= (1e-3 if not bf else 5e-2), ("grad", worst)
         lg, pres = m(x)
         want, opast, _ = orc.forward(x)
