@@ -2104,10 +2104,11 @@ static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void*
             }();
             CMP_REQUIRE(attr_ks, "attention: the key-split backward kernels do not get %zu bytes of LDS", smem_ks);
             const double flk = (double)B * H * (double)Tn * Tn * D;
-            // The c_attn bias gradient (column sums of [dQ | dK | dV]) is NOT fused here: every workgroup of a head adds to the same 16
-            // addresses, and device-scope float atomics on one address retire ~0.5 us apart -- 16.5 of the 29.4 us of the dK/dV launch
-            // and ~4 of dQ's 19 at the default configuration (measurement builds, profiles/r5_06).  A column-sum pass over the
-            // [tokens, 3E] gradient costs ~5 us at these sizes (63 us at the benchmark's, where the fused sums stay).
+            // The c_attn bias gradient (column sums of [dQ | dK | dV]) is NOT fused here: a fused sum ends a workgroup on a transpose-reduce
+            // and a device-scope float atomic whose round trip the launch has to wait out -- 16.5 of the 29.4 us of the dK/dV launch (two
+            // sums) and ~8 of dQ's 19 at the default configuration (measurement builds, profiles/r5_06); only a launch of several rounds
+            // hides that tail behind other workgroups.  A column-sum pass over the [tokens, 3E] gradient costs ~5 us at these sizes (63 us
+            // at the benchmark's, where the fused sums stay).
             float* const bias_out = bias_grad;
             bias_grad = nullptr;
             auto bias_pass = [&]() -> int {
