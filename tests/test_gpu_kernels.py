@@ -7,6 +7,7 @@ bf16 mode: inputs are rounded to bf16 first, then the comparison allows the bf16
 """
 import ctypes as C
 import math
+import os
 import numpy as np
 import pytest
 import torch
@@ -511,7 +512,9 @@ def test_attention_bias_gradient_paths(lib, B, H, D, T, p, fused):
     ck(lib, lib.cmp_attn_bwd_bias_next(P(bias)))
     ck(lib, lib.cmp_k_attn_bwd(stream(), P(qkv), P(o), P(do), P(lse), P(delta), P(dqkv), B, T, H, D, 1, BF16, p, 5, 3))
     torch.cuda.synchronize()
+    mib = int(os.environ.get("COMPOSER_ATTN_BIAS_PASS", "16"))          # (the measurement override moves the bound; the forms stay right)
     assert (B * T * 3 * E * 2 > 16 << 20) == fused
+    fused = B * T * 3 * E * 2 > mib << 20
     want = dqkv.double().sum(0).cpu() + 7.0
     scale = dqkv.double().abs().sum(0).cpu().clamp_min(1e-30)           # rounding of the summands is relative to their magnitudes
     err = ((bias.double().cpu() - want).abs() / scale).max().item()
