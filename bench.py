@@ -21,7 +21,14 @@ roofline of EVERY kernel class of the step, three extra steps each; every entry 
 profiles/hbm_traffic.json covers the run, the PMC-measured in-step `traffic`), `b32` (SURVEY's C2 batch, 32 sequences, with its
 own `classes`) and `c4` (BASELINE config 4), each `{ms_per_step, value, model_mfma_frac}` from 3 warm-up + 10 timed steps, and
 `forward` (the north-star quantity: the inference forward pass of C2 and C4 as a fraction of the bf16 MFMA peak).
-Under a launcher (any N, also 1) the line carries `comm`: the gradient exchange's exposed (non-overlapped) time per step.
+Under a launcher (any N, also 1) the line carries `comm`: the gradient exchange's exposed (non-overlapped) time per step, `ranks`
+(every rank's own ms/step and exposed ms, gathered over gloo -- a straggler shows up by rank) and `runtime` (RCCL version and the
+paths of the RCCL / HIP runtime this process is bound to); RCCL's own diagnostics (NCCL_DEBUG, default WARN) go to stderr: under
+a launcher fd 1 points at stderr for the whole run and the JSON line is written to the original stdout.
+
+  python bench.py --gpus N --allreduce-only [--steps K]
+times the gradient exchange of one step ALONE -- the product's own message pattern (3-float metrics message + L+2 fp32 gradient
+buckets, 78.6 MB at C2) back to back on the communication stream, no compute -- and prints algorithm / bus bandwidth.
 """
 import argparse
 import ctypes as C
@@ -419,6 +426,8 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-class roofline table and the b32 / c4 side runs")
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--allreduce-only", action="store_true", help="time the step's gradient-exchange message pattern alone (no compute) and "
+                                                                   "print its algorithm / bus bandwidth; --steps = repetitions")
     ap.add_argument("--hog", default=None, help="measurement aid: 'WGS,USEC' -- before every step, WGS workgroups spin for USEC "
                                                "microseconds on the communication stream (a stand-in for a concurrent RCCL kernel)")
     args = ap.parse_args()
@@ -431,6 +440,19 @@ def main():
         sys.exit(self_launch(args))
     if args.gpus != world and under_launcher:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    if args.allreduce_only and not under_launcher:
+        # (one rank: RCCL copies in place -- the pattern and the plumbing still run; a child, this parent has not touched the GPU)
+        args.gpus = max(1, args.gpus)
+        sys.exit(self_launch(args))
+    json_fd = 1
+    if under_launcher:
+        # RCCL's diagnostics belong on stderr, the ONE JSON line on stdout: fd 1 is pointed at stderr for the whole run (RCCL and gloo
+        # write to it directly), the line goes to the saved descriptor at the end
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -460,6 +482,29 @@ def main():
             dist.broadcast_object_list(uid, src=0)
             model.init_data_parallel(rank, world, uid[0])
             model.synchronize()
+
+    if args.allreduce_only:
+        reps = max(1, args.steps)
+        model.synchronize()
+        dist.barrier()
+        r = model.all_reduce_pattern(reps)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "ms": r["ms"]})
+        if rank == 0:
+            ms = max(g["ms"] for g in gathered)
+            alg = r["bytes"] / (ms * 1e-3) / 1e9
+            out = {"metric": "gradient all-reduce of one train step alone (product bucket pattern, no compute)", "value": alg,
+                   "unit": "GB/s (algorithm bandwidth: bytes of one rank's gradients / time)", "n_gpus": world, "reps": reps,
+                   "ms_per_pattern": ms, "bytes": r["bytes"], "messages": r["messages"],
+                   "bus_bandwidth_gbs": alg * (2.0 * (world - 1) / world if world > 1 else 1.0),
+                   "bus_bandwidth_note": "ring all-reduce moves 2(N-1)/N of the message over every link; xGMI: ~153 GB/s per link "
+                                         "(at N = 1 RCCL copies in place: the figure is a device-memory copy rate)",
+                   "config": {"workload": "%s gradient buckets: %d messages" % (cf["label"], r["messages"])},
+                   "ranks": sorted(gathered, key=lambda g: g["rank"]), "runtime": _lib.runtime_info()}
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        model.close()
+        dist.destroy_process_group()
+        return
 
     # synthetic inputs, resident in HBM before the timed region
     n_data = 4
@@ -507,7 +552,12 @@ def main():
     classes = None
     if world == 1 and not args.no_extras:
         classes = class_table(lib, step, Bq * T, args.config)
+    ranks = None
     if dist.is_initialized():
+        ranks = [None] * world
+        dist.all_gather_object(ranks, {"rank": rank, "ms_per_step": 1e3 * dt / args.steps,
+                                       "exposed_ms": comm["exposed_ms"] if comm else None, "device": local_rank})
+        ranks.sort(key=lambda r: r["rank"])
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -559,6 +609,8 @@ def main():
             out["comm"] = {"exposed_ms": comm["exposed_ms"], "steps": comm["steps"], "bytes": comm["bytes"], "buckets": comm["buckets"],
                            "ranks": world, "note": "fp32 gradient buckets (one per decoder block + ln_f + embeddings) and a 3-float "
                            "metrics message, ncclAllReduce on a highest-priority side stream, Adam per bucket behind its all-reduce"}
+            out["ranks"] = ranks
+            out["runtime"] = _lib.runtime_info()
     model.close()
     if rank == 0:
         if world == 1 and not args.no_extras:
@@ -575,7 +627,8 @@ def main():
                 out["dp1"] = d1
         if world == 1 and not args.no_decode:
             out["decode"] = decode_bench(local_rank)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

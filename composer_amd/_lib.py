@@ -51,6 +51,8 @@ SIGNATURES = {
     "cmp_dp_set_gemm_cus": (_i, [_P, _i]),
     "cmp_dp_set_mask_rank": (_i, [_P, _i]),
     "cmp_dp_stats": (_i, [_P, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i)]),
+    "cmp_dp_rccl_version": (_i, [C.POINTER(_i)]),
+    "cmp_dp_allreduce_pattern": (_i, [_P, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i)]),
     "cmp_model_create": (_i, [_P, C.POINTER(ModelCfg), C.POINTER(_P)]),
     "cmp_model_destroy": (_i, [_P]),
     "cmp_param_count": (_i, [_P, C.POINTER(_i)]),
@@ -110,7 +112,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_dp_init_exchange", "cmp_train_step_graph_probe", "cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
+_ADDED_LATER = {"cmp_dp_rccl_version", "cmp_dp_allreduce_pattern", "cmp_dp_init_exchange", "cmp_train_step_graph_probe", "cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
 
 _lib = None
 
@@ -125,6 +127,7 @@ def load():
             "libcomposer_hip.so not found at %s -- build it with `python -m composer_amd.build` "
             "(hipcc, gfx950).  composer_amd has no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    check_single_runtime()
     for name, (res, args) in SIGNATURES.items():
         if name in _ADDED_LATER and os.environ.get("COMPOSER_HIP_LIB") and not hasattr(lib, name):
             continue
@@ -133,6 +136,55 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_RUNTIME_STEMS = ("libamdhip64", "librccl", "libhsa-runtime64")
+
+
+def mapped_runtime_libraries():
+    """{stem: sorted real paths} of the HIP runtime / RCCL / HSA shared objects mapped into THIS process right now
+    (/proc/self/maps).  One path per stem is the healthy state."""
+    found = {k: set() for k in _RUNTIME_STEMS}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rstrip("\n").split(None, 5)[-1] if line.count("/") else ""
+                base = os.path.basename(path)
+                for stem in _RUNTIME_STEMS:
+                    if base.startswith(stem + ".so"):
+                        found[stem].add(os.path.realpath(path))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+def check_single_runtime():
+    """Raises when two DIFFERENT copies of the HIP runtime, of RCCL or of the HSA runtime are mapped into this process.
+
+    libcomposer_hip.so asks the dynamic linker for `libamdhip64.so.7` / `librccl.so.1` (rpath /opt/rocm/lib); torch's wheel
+    bundles its own copies and asks for them as `libamdhip64.so` / `librccl.so`.  With torch imported FIRST the linker hands the
+    library torch's copies (same SONAME, already loaded): one runtime, one RCCL -- the state bench.py and the test suite run in.
+    With the library loaded first, a later `import torch` maps a second runtime beside /opt/rocm's: a process that then
+    initialises both sees "No HIP GPUs are available" from torch.cuda at best, and its ranks may sit on another RCCL than the
+    peers of the job.  The rule ("Library load order"): a process that uses torch at all imports it before
+    composer_amd loads the library -- `composer_amd.cli` does so itself when WORLD_SIZE > 1."""
+    dup = {k: v for k, v in mapped_runtime_libraries().items() if len(v) > 1}
+    if dup:
+        raise HipLibraryError(
+            "two copies of the GPU runtime are mapped into this process: %s.  libcomposer_hip.so was loaded before torch was "
+            "imported, so it is bound to /opt/rocm's runtime while torch brought its own.  Fix: `import torch` BEFORE the first "
+            "composer_amd call that loads the library (composer_amd._lib.load(), Transformer(...)), or do not import torch in "
+            "this process, or put torch's lib directory first in LD_LIBRARY_PATH so both resolve to the same files."
+            % "; ".join("%s -> %s" % (k, " AND ".join(v)) for k, v in sorted(dup.items())))
+
+
+def runtime_info():
+    """What this process is bound to: the mapped runtime libraries and RCCL's version (for bench.py's multi-GPU line)."""
+    v = C.c_int(0)
+    rc = load().cmp_dp_rccl_version(C.byref(v))
+    libs = mapped_runtime_libraries()
+    return {"rccl_version": v.value if rc == 0 else None, "rccl_path": (libs.get("librccl") or [None])[0],
+            "hip_runtime_path": (libs.get("libamdhip64") or [None])[0]}
 
 
 def last_error():
@@ -145,6 +197,7 @@ def check(rc, what=""):
 
 
 def require_gpu():
+    check_single_runtime()          # (again: torch may have been imported since load())
     n = load().cmp_device_count()
     if n <= 0:
         raise HipLibraryError("no HIP device visible: composer_amd needs an MI355X (gfx950); there is no CPU fallback")

@@ -147,6 +147,11 @@ def _init_distributed(model):
 @click.group()
 @click.option('--verbosity', '-v', default='info', help='Logging level name.')
 def cli(verbosity):
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        # Library load order: a data-parallel job uses torch.distributed (gloo) to hand the RCCL id to the ranks, so
+        # torch comes into this process anyway -- import it BEFORE libcomposer_hip.so is loaded, so that the dynamic linker binds the
+        # library to the HIP runtime and the RCCL torch has already mapped: one runtime, the RCCL bench.py and the tests run on.
+        import torch.distributed  # noqa: F401
     logging.basicConfig(level=getattr(logging, str(verbosity).upper(), logging.INFO), format='%(levelname)s: %(message)s')
 
 

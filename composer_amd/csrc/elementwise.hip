@@ -1219,9 +1219,6 @@ extern "C" int cmp_k_layernorm_fwd(void* stream, const void* x, const float* gam
 // 7.40 / 7.38 / 7.45 / 7.57 ms at 32768 rows (C2, B=32), 26.70 / 26.54 / 26.54 / 26.69 ms at 131072 rows.
 static int ln_bwd_grid(int rows) {
     int cap = 1024;
-#ifdef COMPOSER_EXPERIMENTS
-    if (const char* e = getenv("COMPOSER_LN_BWD_GRID")) cap = atoi(e);
-#endif
     return std::max(1, std::min(cdiv(rows, 8), cap));
 }
 

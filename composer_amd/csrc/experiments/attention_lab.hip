@@ -16,7 +16,11 @@
 //                  dV^T += dO^T.P and dK^T += Q^T.dS; each wave keeps dK^T/dV^T of its 32 keys in registers.
 //   "transposed" A operands (V^T, K^T, Q^T, dO^T) come from row-major LDS images through
 //   ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (fp32).
-#include "common.h"
+#include "../common.h"
+#if !defined(COMPOSER_EXPERIMENTS) || !defined(ATTN_DIAG)      // measurement ladders exist in experiments builds only
+#undef ATTN_DIAG
+#define ATTN_DIAG 0
+#endif
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -154,7 +158,11 @@ template <typename T, int D, int ROWS = 64> struct Stager {
             const int row = c / CPR, cc = c % CPR;
             // whole chunks per thread (every D >= 32): unconditional, so the stores are straight-line code that can be scheduled
             // among the tile's last MFMAs instead of four exec-masked blocks behind them
+#ifdef ATTN_COND_STORE
+            if (c < ROWS * CPR) {
+#else
             if (WHOLE || c < ROWS * CPR) {
+#endif
                 if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
                     for (int j = 0; j < VN; j++) img[row * S + cc * VN + j] = r[i].get(j);
@@ -406,8 +414,10 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by, int H) {
     const int xcd = L & 7, slot = L >> 3;
     bx = slot % gx;
     by = (slot / gx) * 8 + xcd;
+#ifndef ATTN_NO_HEAD_ROTATE
     const int bb = by / H;
     by = bb * H + (by % H + bb) % H;
+#endif
 }
 
 // Block plan of the forward and dQ launches (plan_u >= 0; 1-D grid, B*H a multiple of 8).  All paired workgroups cost the same
@@ -440,8 +450,10 @@ __device__ __forceinline__ void attn_job(int plan_u, int nb, int H, int& by, int
         qb1 = -1;
     }
     by = row * 8 + xcd;
+#ifndef ATTN_NO_HEAD_ROTATE
     const int bb = by / H;
     by = bb * H + (by % H + bb) % H;
+#endif
 }
 
 // =================================================================================================
@@ -477,7 +489,11 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
     } else {
         attn_job(plan_u, nb, H, by, qb0, qb1);
     }
+#if ATTN_DIAG == 9                                   // measurement build: every batch row aliases row 0 or 1 (data set stays in L2 / MALL)
+    const int b = (by / H) & 1, hd = by % H;
+#else
     const int b = by / H, hd = by % H;
+#endif
     const int E = H * D;
     const int64_t rs = 3 * E;                        // row stride of qkv
     const T* qg = qkv + (int64_t)b * Tn * rs + hd * D;
@@ -490,13 +506,22 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
     // maximum (at most 2^RESCALE_LOG2, exact in fp32 sums and as bf16 operands) and O / l stays the same quotient.  With random
     // scores some row of a wave sets a new maximum in nearly every tile, so the exact vote rescaled (34 multiplies and an
     // exponential per lane) almost always; the deferred one does so on the first tile of a row and rarely after.
+#ifndef ATTN_RESCALE_LOG2
 #define ATTN_RESCALE_LOG2 8.0f
+#endif
     const float rescale_raw = ATTN_RESCALE_LOG2 / c2;
     const float* am = AMASK ? amask + (int64_t)b * Tn : nullptr;
     const float inv_scale = 1.0f / scale;           // throughput mode works on raw scores: the mask term goes in divided by the scale
 
     for (int ph = 0; ph < 2; ph++) {
+#ifdef ATTN_LIGHT_FIRST
+        // the pair's LIGHT query block first: the four pair-workgroups of a (batch, head) row then start on key tile 0 together and
+        // their heavy blocks follow one tile apart -- a sliding window of the row's K/V stays in the XCD's L2 instead of the light
+        // blocks re-reading the first tiles long after the heavy ones streamed past them
+        const int qb = qb1 < 0 ? (ph == 0 ? qb0 : -1) : (ph == 0 ? qb1 : qb0);
+#else
         const int qb = ph == 0 ? qb0 : qb1;
+#endif
         if (qb < 0) break;
         const int q0w = KS ? qb * 32 : qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
@@ -530,10 +555,17 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
             const T* Vs = Ks + IMG;
             const bool more = kts + KT < kv_end;
             const int kt0 = kts + wk;                 // first key of this wave's 64
+#if ATTN_DIAG == 7          // every tile load re-reads tile 0 (L1 / L2 hits): instruction issue without the traffic
+            if (more) {
+                sk.load(kg, rs, decltype(interior)::value ? 0 : kts + KT, Tn, tid);
+                sv.load(vg, rs, decltype(interior)::value ? 0 : kts + KT, Tn, tid);
+            }
+#elif ATTN_DIAG != 5
             if (more) {
                 sk.load(kg, rs, kts + KT, Tn, tid);
                 sv.load(vg, rs, kts + KT, Tn, tid);
             }
+#endif
             // Fast path (throughput mode): all 64 keys of the tile are at or below every query of this wave -> no
             // masking; both 32-key sub-tiles go through ONE softmax step: 8 score MFMAs back to back, one row-max exchange
             // and one rescale vote per 64 keys, 32 exponentials, 8 PV MFMAs.
@@ -542,8 +574,16 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
                 f32x16 s0, s1;
 #pragma unroll
                 for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
+                // ATTN_DIAG (measurement builds only -- results are wrong; tools/kbench.py attn):
+                // 1 no exponentials, 2 no PV MFMAs, 3 no score MFMAs / K fragment reads, 4 no staging stores and no barrier,
+                // 5 no global loads either, 6 no row max / rescale
+#if ATTN_DIAG == 3
+#pragma unroll
+                for (int r = 0; r < 16; r++) { s0[r] = (float)(kt0 + r) * 1e-3f; s1[r] = (float)(kt0 - r) * 1e-3f; }
+#else
                 s0 = mma_rows<T, D>(Ks, 0, qf, lane, s0);
                 s1 = mma_rows<T, D>(Ks, 32, qf, lane, s1);
+#endif
                 if constexpr (AMASK) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
@@ -551,7 +591,11 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
                         s1[r] += am[kt0 + 32 + rho(r, h)] * inv_scale;
                     }
                 }
+#if ATTN_DIAG == 6
+                const float mloc = 0.f;
+#else
                 const float mloc = half_max(fmaxf(max16(s0), max16(s1)));
+#endif
                 const float mnew = fmaxf(m, mloc);
                 if (!__all(mnew <= m + rescale_raw)) {
                     const float alpha = fast_exp2((m - mnew) * c2);
@@ -564,18 +608,28 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
                 }
                 const float mc = m * c2;
                 f32x2 ps = {0.f, 0.f};
+#if ATTN_DIAG == 1
+#pragma unroll
+                for (int r = 0; r < 16; r++) { s0[r] = fmaf(s0[r], c2, -mc); s1[r] = fmaf(s1[r], c2, -mc); ps[0] += s0[r]; ps[1] += s1[r]; }
+#else
                 ps = exp2_scaled16(s0, c2, -mc, ps);
                 ps = exp2_scaled16(s1, c2, -mc, ps);
+#endif
                 lsum += ps[0] + ps[1];
                 if constexpr (DROP) {
                     mask16_qlane<true>(s0, rowh, kt0, h, drop.thr);
                     mask16_qlane<true>(s1, rowh, kt0 + 32, h, drop.thr);
                 }
+#if ATTN_DIAG == 2
+#pragma unroll
+                for (int r = 0; r < 16; r++) { oacc[0][r] += s0[r]; oacc[G::DT - 1][r] += s1[r]; }
+#else
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) {
                     oacc[dt] = mma_acc_b<T, D>(Vs, 0, dt, s0, lane, oacc[dt]);
                     oacc[dt] = mma_acc_b<T, D>(Vs, 32, dt, s1, lane, oacc[dt]);
                 }
+#endif
             } else
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
@@ -651,12 +705,18 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
 #pragma unroll
                 for (int dt = 0; dt < G::DT; dt++) oacc[dt] = mma_acc_b<T, D>(Vs, 32 * sub, dt, s, lane, oacc[dt]);
             }
+#if ATTN_DIAG == 4 || ATTN_DIAG == 5
+            if (!decltype(interior)::value) {
+#endif
             if (more) {
                 T* nbuf = Kb + ((it & 1) ^ 1) * 2 * IMG;
                 sk.store(nbuf, tid);
                 sv.store(nbuf + IMG, tid);
             }
             __syncthreads();
+#if ATTN_DIAG == 4 || ATTN_DIAG == 5
+            }
+#endif
         };
         int kt0 = 0, it = 0;
         const int interior_end = EXACT ? 0 : (qb * QR) / KT * KT;      // whole tiles below every query row of the block
@@ -706,6 +766,701 @@ __global__ __launch_bounds__(256, (KS ? 2 : Occ<T, D>::MINW_Q)) void attn_fwd_ke
     }
 }
 
+#ifdef COMPOSER_EXPERIMENTS
+// Three more forward structures for bf16 / D = 64, built and measured in round 3 (profiles/NEGATIVE_RESULTS.md, "Attention"): none beats
+// the kernel above.  They are NOT part of the product library: `python tools/ab_build.py <name> attention.hip -DCOMPOSER_EXPERIMENTS`
+// builds a library that has them (COMPOSER_ATTN64=force|pipe|dense selects one), tests/extra/test_gpu_attn64.py runs them.
+// =================================================================================================
+// forward, bf16 / D = 64, second structure ("fwd64").  What round 2 measured on the kernel above: no pipe is busy (matrix
+// 25 %, vector ~30-50 %, LDS 33 %) -- the waves wait: for the register-staged K/V loads (-26 % without them), for the
+// staging stores and for a barrier every 16 MFMAs.  Here
+//   * a wave owns 64 query rows (two 32-row blocks), so a staged 64-key tile feeds 32 MFMAs per wave between barriers and
+//     every K / V fragment read from LDS is used twice;
+//   * K and V tiles reach LDS by LDS-DMA (buffer_load ... lds, issued from inline asm so that hipcc's wait-count pass
+//     never sees a pending LDS write) into a 3-stage ring: two tiles in flight behind counted s_waitcnt vmcnt, no staging
+//     registers, no staging stores, ONE raw s_barrier per tile;
+//   * the LDS images are lane-linear (what the DMA writes), 128-byte rows; the bank-conflict swizzles sit on the per-lane
+//     SOURCE address and on the read address: K (ds_read_b128 by rows) 16-byte chunk ^ ((row >> 1) & 7), V
+//     (ds_read_b64_tr_b16) 64-byte half ^ ((row >> 1) & 1);
+//   * 256 threads, 2 workgroups per CU (256 registers per wave, 48 KiB of LDS each): two independent workgroups per SIMD
+//     interleave matrix and vector work.
+// A workgroup takes a PAIR of 256-row query blocks (heaviest with lightest, as above); inside a block wave w owns the
+// 32-row blocks w and 7-w.  Tiles below the block are mask-free; the (up to four) tiles on the diagonal are masked by
+// comparison in every wave (masked probabilities are exactly 0), which keeps every accumulating MFMA out of branches.
+// =================================================================================================
+typedef int a2_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char a2_lds_char;
+__device__ __forceinline__ a2_v4i a2_make_srd(const void* base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    a2_v4i d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xFFFFu));
+    d[2] = __builtin_amdgcn_readfirstlane((int)min(bytes, (int64_t)0x7FFFFFF0));
+    d[3] = 0x00020000;
+    return d;
+}
+// one 1-KiB LDS-DMA piece: LDS [lds_addr, +1024) <- 16 bytes per lane from base + voff + soff (range-checked: zeros past the end)
+__device__ __forceinline__ void a2_dma16(a2_v4i srd, uint32_t lds_addr, int voff, int soff) {
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+#pragma unroll
+    for (int i = 0; i < 4; i++) srd[i] = __builtin_amdgcn_readfirstlane(srd[i]);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+                 : "memory", "m0");
+}
+#ifndef A2_STAGES
+#define A2_STAGES 3                 // ring stages: A2_STAGES - 1 tiles in flight
+#endif
+#define A2_IMG 8192                 // one [64 keys][64 d] bf16 image
+// A2_DIAG (measurement builds only -- results are wrong; tools/attn_ab.sh): 1 no exponentials, 2 no softmax arithmetic at all,
+// 3 no DMA inside the tile loop, 4 no barrier / counted waits, 5 no PV MFMAs, 6 no score MFMAs, 8 one workgroup per CU
+#ifndef A2_DIAG
+#define A2_DIAG 0
+#endif
+#if A2_DIAG == 8
+#define A2_MINW 1
+#else
+#define A2_MINW 2
+#endif
+#define A2_STAGE (2 * A2_IMG)
+
+template <bool DROP>
+__global__ __launch_bounds__(256, A2_MINW) void attn_fwd64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int Tn, int H, float scale, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    xcd_block(bx, by, H);
+    const int b = by / H, hd = by % H;
+    const int E = H * 64;
+    const int64_t rs = 3 * E;
+    const bf16_t* qg = qkv + (int64_t)b * Tn * rs + hd * 64;
+    bf16_t* og = o + (int64_t)b * Tn * E + hd * 64;
+    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const int nb = cdiv(Tn, 256);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(a2_lds_char*)smem_raw;
+    const int64_t span = ((int64_t)(Tn - 1) * rs + 64) * 2;
+    const a2_v4i srk = a2_make_srd(qg + E, span), srv = a2_make_srd(qg + 2 * E, span);
+    const int rsb = (int)(rs * 2);                                       // row stride in bytes
+    // this wave's DMA pieces: pieces 2w, 2w+1 of the K image and of the V image (8 rows x 128 B each)
+    int kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), pc = lane & 7;
+        kvo[i] = row * rsb + ((pc ^ ((row >> 1) & 7)) << 4);
+        vvo[i] = row * rsb + ((pc ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    auto issue = [&](int t, int stage) {
+        const int soff = t * 64 * rsb;
+        const uint32_t kb = lds0 + stage * A2_STAGE + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srk, kb + i * 1024, kvo[i], soff);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srv, kb + A2_IMG + i * 1024, vvo[i], soff);
+    };
+    // fragment read addresses (byte offsets inside an image)
+    int koff[4];                                                        // K rows: lane = key row, chunk 2s + h
+#pragma unroll
+    for (int s = 0; s < 4; s++) koff[s] = (lane & 31) * 128 + (((2 * s + h) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int G = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    int voffr[2];                                                       // V transposed reads: dt = 0, 1
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) voffr[dt] = (4 * (G >> 1) + qq) * 128 + ((dt ^ ((qq >> 1) & 1)) << 6) + 32 * (G & 1) + 8 * pp;
+
+    for (int ph = 0; ph < 2; ph++) {
+        const int hi = nb - 1 - bx;
+        const int qb = ph == 0 ? hi : (bx < hi ? bx : -1);
+        if (qb < 0) break;
+        int q0[2] = {qb * 256 + 32 * wave, qb * 256 + 32 * (7 - wave)};
+        int q[2];
+        bool qvalid[2];
+        bf16x8 qf[2][4];
+        uint32_t rowh[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            q[i] = q0[i] + (lane & 31);
+            qvalid[i] = q[i] < Tn;
+            load_bfrags<bf16_t, 64>(qf[i], qg, rs, q[i], qvalid[i], h);
+            rowh[i] = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q[i]));
+        }
+        f32x16 oacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc[i][dt][r] = 0.f;
+        float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+        const int kv_end = min(Tn, qb * 256 + 256);
+        const int nt = cdiv(kv_end, 64), nint = qb * 4;                  // tiles; the first nint lie below every query row of the block
+#pragma unroll
+        for (int i = 0; i < A2_STAGES - 1; i++)
+            if (i < nt) issue(i, i);
+
+        // one 64-key tile for both 32-row blocks of this wave; MASK (compile time): compare keys with queries / Tn
+        auto tile = [&](auto MASKT, const int t, const int st) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(MASKT)::value;
+            const char* Ks = smem_raw + st * A2_STAGE;
+            const char* Vs = Ks + A2_IMG;
+            bf16x8 kf[2][4];
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) kf[sub][s] = *reinterpret_cast<const bf16x8*>(Ks + sub * 4096 + koff[s]);
+            f32x16 sc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sc[i][sub][r] = 0.f;
+#pragma unroll
+#if A2_DIAG == 6
+                    for (int r = 0; r < 16; r++) sc[i][sub][r] = (float)kf[sub][r & 3][r & 7] * 1e-3f + (float)(t + r);
+#else
+                    for (int s = 0; s < 4; s++) sc[i][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][s], qf[i][s], sc[i][sub], 0, 0, 0);
+#endif
+                }
+            bf16x8 pb[2][2][2];                                          // [block][sub][k-step]: probabilities as the B operand
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (MASK) {
+#pragma unroll
+                    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int key = t * 64 + 32 * sub + rho(r, h);
+                            if (key > q[i] || key >= Tn) sc[i][sub][r] = neg_big;      // == -1e4 after scaling (transformer.py:354)
+                        }
+                }
+#if A2_DIAG == 2
+                if (false) {
+#else
+                {
+#endif
+                const float mloc = half_max(fmaxf(max16(sc[i][0]), max16(sc[i][1])));
+                const float mnew = fmaxf(m[i], mloc);
+                if (!__all(mnew == m[i])) {
+                    const float alpha = fast_exp2((m[i] - mnew) * c2);
+                    lsum[i] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) oacc[i][dt][r] *= alpha;
+                    m[i] = mnew;
+                }
+                const float mc = m[i] * c2;
+                f32x2 ps = {0.f, 0.f};
+#if A2_DIAG == 1
+#pragma unroll
+                for (int r = 0; r < 16; r++) { sc[i][0][r] = fmaf(sc[i][0][r], c2, -mc); sc[i][1][r] = fmaf(sc[i][1][r], c2, -mc); ps[0] += sc[i][0][r]; ps[1] += sc[i][1][r]; }
+#else
+                ps = exp2_scaled16(sc[i][0], c2, -mc, ps);
+                ps = exp2_scaled16(sc[i][1], c2, -mc, ps);
+#endif
+                lsum[i] += ps[0] + ps[1];
+                }
+                if constexpr (DROP) {
+                    mask16_qlane<true>(sc[i][0], rowh[i], t * 64, h, drop.thr);
+                    mask16_qlane<true>(sc[i][1], rowh[i], t * 64 + 32, h, drop.thr);
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) pb[i][sub][s][j] = (bf16_t)sc[i][sub][8 * s + j];
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++) {
+                        const char* va = Vs + (32 * sub + 16 * s) * 128 + voffr[dt];
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va));
+                        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(va + 8 * 128));
+                        bf16x8 a;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { a[j] = lo[j]; a[4 + j] = hi4[j]; }
+#pragma unroll
+                        for (int i = 0; i < 2; i++) {
+#if A2_DIAG == 5
+                            asm volatile("" ::"v"(a), "v"(pb[i][sub][s]));
+                            oacc[i][dt][(sub * 2 + s) & 15] += 1.0f;
+#else
+                            oacc[i][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[i][sub][s], oacc[i][dt], 0, 0, 0);
+#endif
+                        }
+                    }
+        };
+        auto step = [&](auto MASKT, const int t) __attribute__((always_inline)) {
+            // tile t has landed: this wave's pieces by the counted wait (the younger tiles' pieces may still fly), the others' by the
+            // barrier; past the barrier every wave has left tile t-1, whose stage takes tile t + A2_STAGES - 1
+#if A2_DIAG != 4
+            {
+                const int ahead = min(nt - 1 - t, A2_STAGES - 2);       // younger tiles that may stay in flight (4 pieces each)
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+#if A2_DIAG != 3
+            if (t + A2_STAGES - 1 < nt) issue(t + A2_STAGES - 1, (t + A2_STAGES - 1) % A2_STAGES);
+#endif
+            tile(MASKT, t, t % A2_STAGES);
+        };
+        int t = 0;
+        for (; t < nint; t++) step(std::false_type{}, t);
+        for (; t < nt; t++) step(std::true_type{}, t);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float ltot = half_sum(lsum[i]);
+            const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q[i], qvalid[i], dt, oacc[i][dt], inv, h);
+            if (qvalid[i] && h == 0) lse[(int64_t)by * Tn + q[i]] = m[i] * scale + logf(ltot);
+        }
+        // the second block's first tiles go into stages the slower waves may still be reading
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// =================================================================================================
+// forward, bf16 / D = 64, third structure ("fwd32p"): software-pipelined across 32-key units inside ONE wave.
+// The unit of work is a 32-key sub-tile u with three stages -- S_u = K_u Q^T (4 MFMAs), softmax(S_u) -> P_u (vector),
+// O += V_u^T P_u (4 MFMAs) -- and the instruction stream of step u is { MFMAs of S_{u+1} and of PV_{u-1} } interleaved with
+// { softmax of unit u }: the vector work always has eight independent MFMAs to sit between, and the LDS operands of step u+1
+// are read at the end of step u.  A wave owns 32 query rows; K/V tiles come through the LDS-DMA ring of the kernel above with
+// FIVE stages (tiles t-1, t, t+1 are read in iteration t; t+2 and t+3 are in flight), one barrier per 64-key tile.
+// The online-softmax rescale of O for unit u is applied AFTER PV_{u-1} has been accumulated (P_{u-1} was scaled with the old
+// running maximum).  Selected by COMPOSER_ATTN64=pipe; measurements in DESIGN.md "Attention, round 3".
+// =================================================================================================
+#define A3_STAGES 5
+#ifndef A3_PIN
+#define A3_PIN 1
+#endif
+// A3_DIAG (measurement builds only -- results are wrong), a bit mask: 1 no exponentials, 2 no softmax arithmetic, 4 no
+// running-maximum head, 8 no barrier / waits / DMA inside the loop, 16 no MFMAs, 32 no V reads from LDS, 64 no K reads from LDS,
+// 128 every batch row aliases batch row 0 or 1 (the whole data set stays in L2 / MALL), 256 no output stores, 512 no prologue DMA, 1024 one tile per block
+#ifndef A3_DIAG
+#define A3_DIAG 0
+#endif
+#define A3D(bit) ((A3_DIAG & (bit)) != 0)
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                             float* __restrict__ lse, int Tn, int H, float scale, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    xcd_block(bx, by, H);
+#if A3D(128)
+    const int b = (by / H) & 1, hd = by % H;
+#else
+    const int b = by / H, hd = by % H;
+#endif
+    const int E = H * 64;
+    const int64_t rs = 3 * E;
+    const bf16_t* qg = qkv + (int64_t)b * Tn * rs + hd * 64;
+    bf16_t* og = o + (int64_t)b * Tn * E + hd * 64;
+    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const int nb = cdiv(Tn, 128);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(a2_lds_char*)smem_raw;
+    const int64_t span = ((int64_t)(Tn - 1) * rs + 64) * 2;
+    const a2_v4i srk = a2_make_srd(qg + E, span), srv = a2_make_srd(qg + 2 * E, span);
+    const int rsb = (int)(rs * 2);
+    int kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), pc = lane & 7;
+        kvo[i] = row * rsb + ((pc ^ ((row >> 1) & 7)) << 4);
+        vvo[i] = row * rsb + ((pc ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    auto issue = [&](int t) {
+        const int soff = t * 64 * rsb;
+        const uint32_t kb = lds0 + (t % A3_STAGES) * A2_STAGE + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srk, kb + i * 1024, kvo[i], soff);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srv, kb + A2_IMG + i * 1024, vvo[i], soff);
+    };
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) koff[s] = (lane & 31) * 128 + (((2 * s + h) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int G = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    int voffr[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) voffr[dt] = (4 * (G >> 1) + qq) * 128 + ((dt ^ ((qq >> 1) & 1)) << 6) + 32 * (G & 1) + 8 * pp;
+
+    for (int ph = 0; ph < 2; ph++) {
+        const int hi = nb - 1 - bx;
+        const int qb = ph == 0 ? hi : (bx < hi ? bx : -1);
+        if (qb < 0) break;
+        const int q = qb * 128 + 32 * wave + (lane & 31);
+        const bool qvalid = q < Tn;
+        bf16x8 qf[4];
+        load_bfrags<bf16_t, 64>(qf, qg, rs, q, qvalid, h);
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
+        f32x16 oacc[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+        const int kv_end = min(Tn, qb * 128 + 128);
+#if A3D(1024)
+        const int nt = 1, nint = 0;
+#else
+        const int nt = cdiv(kv_end, 64), nint = qb * 2;                  // tiles; the first nint lie below every query row of the block
+#endif
+#if !A3D(512)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (i < nt) issue(i);
+#endif
+
+        f32x16 scA, scB;
+        bf16x8 pbA[2], pbB[2];
+        bf16x8 kf[4], va[2][2];                                             // operands of the NEXT step's MFMAs, read one step ahead
+        auto load_k = [&](const char* Kn) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) kf[s] = *reinterpret_cast<const bf16x8*>(Kn + koff[s]);
+        };
+        auto load_v = [&](const char* Vp) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const char* a = Vp + (16 * s) * 128 + voffr[dt];
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
+                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 8 * 128));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { va[s][dt][j] = lo[j]; va[s][dt][4 + j] = hi4[j]; }
+                }
+        };
+        // one pipeline step: softmax of `cur` (unit with first key k0) -> pcur, while the matrix pipe computes nxt = K Q^T (kf) and,
+        // when PV, O += V^T pprev (va); then the operands of the following step are read (Kn2: its K rows, Vp2: its V rows)
+        auto unit = [&](auto MASKT, auto PVT, f32x16& cur, f32x16& nxt, bf16x8 (&pcur)[2], const bf16x8 (&pprev)[2], const char* Kn2,
+                        const char* Vp2, const int k0) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(MASKT)::value;
+            constexpr bool PV = decltype(PVT)::value;
+            if (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = k0 + rho(r, h);
+                    if (key > q || key >= Tn) cur[r] = neg_big;
+                }
+            }
+#if A3D(4)
+            const bool need = false;
+            float alpha = 1.0f;
+            if (m < -1e30f) m = 8.0f;
+#else
+            const float mloc = half_max(max16(cur));
+            const float mnew = fmaxf(m, mloc);
+            const bool need = !__all(mnew == m);
+            float alpha = 1.0f;
+            if (need) {
+                alpha = fast_exp2((m - mnew) * c2);
+                lsum *= alpha;
+                m = mnew;
+            }
+#endif
+            const float mc = m * c2;
+            __builtin_amdgcn_sched_barrier(0);
+#if A3D(16)
+#pragma unroll
+            for (int r = 0; r < 16; r++) nxt[r] = (float)kf[r & 3][r & 7] * 1e-3f + (float)(k0 + r);
+            if (PV) {
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++) { asm volatile("" ::"v"(va[s][dt]), "v"(pprev[s])); oacc[dt][(2 * s + dt) & 15] += 1.0f; }
+            }
+#else
+#pragma unroll
+            for (int r = 0; r < 16; r++) nxt[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], nxt, 0, 0, 0);
+            if (PV) {
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pprev[s], oacc[dt], 0, 0, 0);
+            }
+#endif
+#if A3D(2)
+            f32x2 ps = {cur[0], cur[1]};
+#elif A3D(1)
+            f32x2 ps = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r++) { cur[r] = fmaf(cur[r], c2, -mc); ps[r & 1] += cur[r]; }
+#else
+            f32x2 ps = exp2_scaled16(cur, c2, -mc, f32x2{0.f, 0.f});
+#endif
+            lsum += ps[0] + ps[1];
+#if !A3D(2)
+            if constexpr (DROP) mask16_qlane<true>(cur, rowh, k0, h, drop.thr);
+#endif
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) pcur[s][j] = (bf16_t)cur[8 * s + j];
+#if A3_PIN
+            // pinned interleave: one MFMA per slice of the vector work
+#pragma unroll
+            for (int i = 0; i < (PV ? 8 : 4); i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, DROP ? (PV ? 12 : 24) : (PV ? 5 : 10), 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, PV ? 2 : 4, 0);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(pcur[0]), "+v"(pcur[1]), "+v"(lsum));     // keeps the vector work of this unit inside this block
+#if !A3D(64)
+            load_k(Kn2);
+#endif
+#if !A3D(32)
+            load_v(Vp2);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (need) {                                                     // rescale O AFTER P_{u-1} (old maximum) went in
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+            }
+        };
+        auto iter = [&](auto MASKT, auto FIRSTT, const int t) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(FIRSTT)::value;
+            // tiles <= t + 1 have landed (own pieces: counted wait; the others': the barrier); tile t + 2 may still fly.  The LDS reads
+            // in flight here (operands of step A, tiles t-1 and t) do not touch the stage that is re-filled below (tile t-2's).
+#if !A3D(8)
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 3 < nt) issue(t + 3);
+#endif
+            const char* St = smem_raw + (t % A3_STAGES) * A2_STAGE;
+            const char* Sn = smem_raw + ((t + 1) % A3_STAGES) * A2_STAGE;
+            // step A: unit 2t (S_{2t+1} from K(t) rows 32.., PV of unit 2t-1); then read step B's operands: K(t+1) rows 0.., V(t) rows 0..
+            unit(MASKT, std::integral_constant<bool, !FIRST>{}, scA, scB, pbA, pbB, Sn, St + A2_IMG, t * 64);
+            // step B: unit 2t+1; then step A(t+1)'s operands: K(t+1) rows 32.., V(t) rows 32..
+            unit(MASKT, std::true_type{}, scB, scA, pbB, pbA, Sn + 4096, St + A2_IMG + 32 * 128, t * 64 + 32);
+        };
+        // prologue: S_0, and the operands of step A(0): K(0) rows 32.. (no PV in the very first step)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_k(smem_raw);
+#pragma unroll
+        for (int r = 0; r < 16; r++) scA[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) scA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], scA, 0, 0, 0);
+        load_k(smem_raw + 4096);
+        load_v(smem_raw + A2_IMG);                                          // unused by the first step (finite or not: never multiplied)
+        if (nint > 0) iter(std::false_type{}, std::true_type{}, 0);
+        else iter(std::true_type{}, std::true_type{}, 0);
+        int t = 1;
+        for (; t < nint; t++) iter(std::false_type{}, std::false_type{}, t);
+        for (; t < nt; t++) iter(std::true_type{}, std::false_type{}, t);
+        // drain: PV of the last unit (its V rows were read by the last step)
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pbB[s], oacc[dt], 0, 0, 0);
+        const float ltot = half_sum(lsum);
+        const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#if A3D(256)
+        if (inv == 123.456f)
+#endif
+        {
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q, qvalid, dt, oacc[dt], inv, h);
+            if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = m * scale + logf(ltot);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// =================================================================================================
+// forward, bf16 / D = 64, fourth structure ("fwd32d"): the occupancy experiment.  The round-2 tile body (a 32-key unit at a time:
+// 4 score MFMAs, softmax, 4 PV MFMAs; 32 query rows per wave) fed by the LDS-DMA ring instead of register-staged loads, so that
+// the per-lane state fits 128 registers and FOUR workgroups share a CU (4 waves per SIMD; two ring stages = 32 KiB each).
+// Selected by COMPOSER_ATTN64=dense.
+// =================================================================================================
+#ifndef A4_MINW
+#define A4_MINW 4
+#endif
+#ifndef A4_STAGES
+#define A4_STAGES 2
+#endif
+template <bool DROP>
+__global__ __launch_bounds__(256, A4_MINW) void attn_fwd32d_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                                  float* __restrict__ lse, int Tn, int H, float scale, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    xcd_block(bx, by, H);
+    const int b = by / H, hd = by % H;
+    const int E = H * 64;
+    const int64_t rs = 3 * E;
+    const bf16_t* qg = qkv + (int64_t)b * Tn * rs + hd * 64;
+    bf16_t* og = o + (int64_t)b * Tn * E + hd * 64;
+    const float c2 = scale * LOG2E_F, neg_big = -1e4f / scale;
+    const int nb = cdiv(Tn, 128);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(a2_lds_char*)smem_raw;
+    const int64_t span = ((int64_t)(Tn - 1) * rs + 64) * 2;
+    const a2_v4i srk = a2_make_srd(qg + E, span), srv = a2_make_srd(qg + 2 * E, span);
+    const int rsb = (int)(rs * 2);
+    int kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = 8 * (2 * wave + i) + (lane >> 3), pc = lane & 7;
+        kvo[i] = row * rsb + ((pc ^ ((row >> 1) & 7)) << 4);
+        vvo[i] = row * rsb + ((pc ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    auto issue = [&](int t) {
+        const int soff = t * 64 * rsb;
+        const uint32_t kb = lds0 + (t % A4_STAGES) * A2_STAGE + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srk, kb + i * 1024, kvo[i], soff);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a2_dma16(srv, kb + A2_IMG + i * 1024, vvo[i], soff);
+    };
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) koff[s] = (lane & 31) * 128 + (((2 * s + h) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int G = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    int voffr[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) voffr[dt] = (4 * (G >> 1) + qq) * 128 + ((dt ^ ((qq >> 1) & 1)) << 6) + 32 * (G & 1) + 8 * pp;
+
+    for (int ph = 0; ph < 2; ph++) {
+        const int hi = nb - 1 - bx;
+        const int qb = ph == 0 ? hi : (bx < hi ? bx : -1);
+        if (qb < 0) break;
+        const int q0w = qb * 128 + 32 * wave;
+        const int q = q0w + (lane & 31);
+        const bool qvalid = q < Tn;
+        bf16x8 qf[4];
+        load_bfrags<bf16_t, 64>(qf, qg, rs, q, qvalid, h);
+        const uint32_t rowh = attn_row_hash(drop.seed, drop.stream, (uint32_t)(by * Tn + q));
+        f32x16 oacc[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+        const int kv_end = min(Tn, qb * 128 + 128);
+        const int nt = cdiv(kv_end, 64), nint = qb * 2;
+#pragma unroll
+        for (int i = 0; i < A4_STAGES - 1; i++)
+            if (i < nt) issue(i);
+
+        // one 32-key unit, complete: scores, online softmax, PV.  MASK (compile time): compare keys with queries / Tn
+        auto unit = [&](auto MASKT, const char* Ku, const char* Vu, const int k0) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(MASKT)::value;
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ku + koff[s]);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
+            }
+            if (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = k0 + rho(r, h);
+                    if (key > q || key >= Tn) sc[r] = neg_big;
+                }
+            }
+            const float mloc = half_max(max16(sc));
+            const float mnew = fmaxf(m, mloc);
+            if (!__all(mnew == m)) {
+                const float alpha = fast_exp2((m - mnew) * c2);
+                lsum *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+                m = mnew;
+            }
+            const float mc = m * c2;
+            const f32x2 ps = exp2_scaled16(sc, c2, -mc, f32x2{0.f, 0.f});
+            lsum += ps[0] + ps[1];
+            if constexpr (DROP) mask16_qlane<true>(sc, rowh, k0, h, drop.thr);
+            bf16x8 pb[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) pb[s][j] = (bf16_t)sc[8 * s + j];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const char* a = Vu + (16 * s) * 128 + voffr[dt];
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
+                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 8 * 128));
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi4[j]; }
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, pb[s], oacc[dt], 0, 0, 0);
+                }
+        };
+        auto step = [&](auto MASKT, const int t) __attribute__((always_inline)) {
+            // tile t has landed (own pieces: counted wait; the others': the barrier); every wave has left tile t-1, whose stage is re-filled
+            {
+                const int ahead = min(nt - 1 - t, A4_STAGES - 2);
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + A4_STAGES - 1 < nt) issue(t + A4_STAGES - 1);
+            const char* Ks = smem_raw + (t % A4_STAGES) * A2_STAGE;
+            const char* Vs = Ks + A2_IMG;
+            unit(MASKT, Ks, Vs, t * 64);
+            // the second unit of a diagonal tile lies entirely above the diagonal for the waves whose rows end below it
+            if (!decltype(MASKT)::value || t * 64 + 32 <= q0w + 31) unit(MASKT, Ks + 4096, Vs + 32 * 128, t * 64 + 32);
+        };
+        int t = 0;
+        for (; t < nint; t++) step(std::false_type{}, t);
+        for (; t < nt; t++) {
+            if (t * 64 <= q0w + 31) step(std::true_type{}, t);
+            else {                                                          // nothing to do in this tile: keep the barrier and the ring going
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t + A4_STAGES - 1 < nt) issue(t + A4_STAGES - 1);
+            }
+        }
+        const float ltot = half_sum(lsum);
+        const float inv = (DROP ? drop.scale : 1.0f) / ltot;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) store_t_tile<bf16_t, 64>(og, E, q, qvalid, dt, oacc[dt], inv, h);
+        if (qvalid && h == 0) lse[(int64_t)by * Tn + q] = m * scale + logf(ltot);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+#endif  // COMPOSER_EXPERIMENTS
 
 // =================================================================================================
 // dQ.  same geometry as forward: dQ^T += K^T . dS^T,  dS^T = P^T * (dP^T - delta),  dP^T = V . dO^T
@@ -749,7 +1504,14 @@ __device__ __forceinline__ void attn_dq_body(const T* __restrict__ qkv, const T*
     const float keep_scale = DROP ? drop.scale : 1.0f;
 
     for (int ph = 0; ph < 2; ph++) {
+#ifdef ATTN_LIGHT_FIRST
+        // the pair's LIGHT query block first: the four pair-workgroups of a (batch, head) row then start on key tile 0 together and
+        // their heavy blocks follow one tile apart -- a sliding window of the row's K/V stays in the XCD's L2 instead of the light
+        // blocks re-reading the first tiles long after the heavy ones streamed past them
+        const int qb = qb1 < 0 ? (ph == 0 ? qb0 : -1) : (ph == 0 ? qb1 : qb0);
+#else
         const int qb = ph == 0 ? qb0 : qb1;
+#endif
         if (qb < 0) break;
         const int q0w = KS ? qb * 32 : qb * 128 + wave * 32;
         const int q = q0w + (lane & 31);
@@ -1176,6 +1938,9 @@ static int attn_plan_u(int Tn, int BH, int wgs_per_cu) {
     const int nb = cdiv(Tn, 128), pairs = (nb + 1) / 2;
     if (nb < 2 || (BH & 7) || (int64_t)pairs * BH < 512 || wgs_per_cu < 1) return -1;
     const int rows_x = BH / 8, slots = 32 * wgs_per_cu;
+#if defined(COMPOSER_EXPERIMENTS)
+    if (const char* e = getenv("COMPOSER_ATTN_PLAN_U")) return std::min(atoi(e), rows_x);     // measurement override
+#endif
     const int rounds = rows_x * pairs / slots;
     const int paired_rows = rounds > 0 ? rounds * slots / pairs : rows_x / 4;
     const int u = rows_x - paired_rows;
@@ -1203,31 +1968,88 @@ template <typename K> static int attn_wgs_per_cu(K kernel, size_t smem) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, smem) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
-// LDS opt-in of the key-split kernels (4 * 256 staged rows), decided once per (type, head size) for all of them together: a device
-// or driver that refuses it keeps the 128-row kernels, forward and backward alike (the GEMM ring falls back to its two-stage loop
-// in the same situation) instead of failing every small-grid attention call.
-template <typename T, int D> static size_t attn_ks_smem() { return 4 * 256 * Geo<T, D>::S * sizeof(T); }
-template <typename T, int D> static bool attn_ks_available() {
-    static const bool ok = [] {
-        const int ks = (int)attn_ks_smem<T, D>(), kv = ks / 2 + 3 * 256 * (int)sizeof(float);
-        const void* big[] = {(const void*)attn_fwd_kernel<T, D, true, false, true>, (const void*)attn_fwd_kernel<T, D, false, false, true>,
-                             (const void*)attn_bwd_ks_kernel<T, D, true>, (const void*)attn_bwd_ks_kernel<T, D, false>,
-                             (const void*)attn_dq_ks_kernel<T, D, true>, (const void*)attn_dq_ks_kernel<T, D, false>};
-        const void* half[] = {(const void*)attn_dkv_ks_kernel<T, D, true>, (const void*)attn_dkv_ks_kernel<T, D, false>};
-        bool good = true;
-        for (const void* f : big) good = good && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ks) == hipSuccess;
-        for (const void* f : half) good = good && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kv) == hipSuccess;
-        if (!good) (void)hipGetLastError();
-        return good;
-    }();
-    return ok;
+#ifdef COMPOSER_EXPERIMENTS
+// COMPOSER_ATTN64=force (read per call) takes the 64-rows-per-wave LDS-DMA forward kernel below (tests/test_gpu_attn64.py runs
+// every shape through it).  It is NOT the default: measured on one box at the C2 shape (B*H = 1024, T = 1024), 289 us without
+// dropout against 264-300 for the kernel above, and 528 us with dropout (its mask arithmetic pushes the 64-row state past 256
+// registers: scratch traffic inside a loop that counts vmcnt by hand) -- DESIGN.md "Attention, round 3".
+static int attn64_mode() {
+    const char* e = getenv("COMPOSER_ATTN64");
+    if (!e) return 0;
+    return e[0] == 'o' ? -1 : (e[0] == 'f' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 'd' ? 3 : 0)));
 }
+#endif
 template <typename T, int D>
 static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B, int Tn, int H, float scale, DropCfg d,
                       const float* amask) {
+#ifdef COMPOSER_EXPERIMENTS
+    if constexpr (std::is_same<T, bf16_t>::value && D == 64) {
+        const int nb = cdiv(Tn, 256), pairs = (nb + 1) / 2;
+        const int mode = attn64_mode();
+        if (mode == 3 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
+            const size_t smem4 = A4_STAGES * A2_STAGE;
+            static bool attr4 = false;
+            if (!attr4) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4));
+                attr4 = true;
+            }
+            const int nb4 = cdiv(Tn, 128);
+            dim3 grid((nb4 + 1) / 2, B * H);
+            const double flops = 2.0 * B * H * (double)Tn * Tn * D;
+            PROF_START(3, s);
+            if (d.thr) attn_fwd32d_kernel<true><<<grid, 256, smem4, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            else attn_fwd32d_kernel<false><<<grid, 256, smem4, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * 64 * 2 + 4.0));
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+        if (mode == 2 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
+            const size_t smem3 = A3_STAGES * A2_STAGE;
+            static bool attr3 = false;
+            if (!attr3) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3));
+                attr3 = true;
+            }
+            const int nb3 = cdiv(Tn, 128);
+            dim3 grid((nb3 + 1) / 2, B * H);
+            const double flops = 2.0 * B * H * (double)Tn * Tn * D;
+            PROF_START(3, s);
+            if (d.thr) attn_fwd32p_kernel<true><<<grid, 256, smem3, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            else attn_fwd32p_kernel<false><<<grid, 256, smem3, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * 64 * 2 + 4.0));
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+        if (mode == 1 && (int64_t)Tn * 3 * H * 64 * 2 < 0x7FFFFFF0ll) {
+            const size_t smem2 = A2_STAGES * A2_STAGE;
+            static bool attr = false;
+            if (!attr) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+                attr = true;
+            }
+            dim3 grid(pairs, B * H);
+            const double flops = 2.0 * B * H * (double)Tn * Tn * D;
+            PROF_START(3, s);
+            if (d.thr) attn_fwd64_kernel<true><<<grid, 256, smem2, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            else attn_fwd64_kernel<false><<<grid, 256, smem2, s>>>((const bf16_t*)qkv, (bf16_t*)o, lse, Tn, H, scale, d);
+            PROF_STOP(3, s, flops, (double)B * Tn * H * (4.0 * 64 * 2 + 4.0));
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+    }
+#endif
     if constexpr (std::is_same<T, bf16_t>::value && D <= 32) {
-        const size_t smem_ks = attn_ks_smem<T, D>();
-        if (!amask && attn_ks_available<T, D>() && attn_key_split(Tn, B * H, D, true)) {
+        if (!amask && attn_key_split(Tn, B * H, D, true)) {
+            const size_t smem_ks = 4 * 256 * Geo<T, D>::S * sizeof(T);
+            static const bool attr_ks = [&] {
+                bool ok = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                return ok;
+            }();
+            CMP_REQUIRE(attr_ks, "attention: the key-split forward kernel does not get %zu bytes of LDS", smem_ks);
             const dim3 grid(cdiv(Tn, 32), B * H);
             PROF_START(3, s);
             if (d.thr) attn_fwd_kernel<T, D, true, false, true><<<grid, 256, smem_ks, s>>>((const T*)qkv, (T*)o, lse, Tn, H, scale, d, -1, nullptr);
@@ -1267,9 +2089,20 @@ template <typename T, int D>
 static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                       void* dqkv, int B, int Tn, int H, float scale, DropCfg d, float* bias_grad) {
     if constexpr (std::is_same<T, bf16_t>::value && D <= 32) {
-        // one launch, both roles: LDS = the larger of the two (dQ double-buffers its 256-key tiles)
-        const size_t smem_ks = attn_ks_smem<T, D>(), smem_kv = smem_ks / 2 + 3 * 256 * sizeof(float);
-        if (attn_ks_available<T, D>() && attn_key_split(Tn, B * H, D, true)) {
+        if (attn_key_split(Tn, B * H, D, true)) {
+            // one launch, both roles: LDS = the larger of the two (dQ double-buffers its 256-key tiles)
+            const size_t smem_ks = 4 * 256 * Geo<T, D>::S * sizeof(T);
+            const size_t smem_kv = smem_ks / 2 + 3 * 256 * sizeof(float);
+            static const bool attr_ks = [&] {
+                bool ok = hipFuncSetAttribute((const void*)attn_bwd_ks_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_bwd_ks_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dq_ks_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dq_ks_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ks) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dkv_ks_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)attn_dkv_ks_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv) == hipSuccess;
+                return ok;
+            }();
+            CMP_REQUIRE(attr_ks, "attention: the key-split backward kernels do not get %zu bytes of LDS", smem_ks);
             const double flk = (double)B * H * (double)Tn * Tn * D;
             // The c_attn bias gradient (column sums of [dQ | dK | dV]) is NOT fused here: a fused sum ends a workgroup on a transpose-reduce
             // and a device-scope float atomic whose round trip the launch has to wait out -- 16.5 of the 29.4 us of the dK/dV launch (two

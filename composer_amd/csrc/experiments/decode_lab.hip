@@ -14,7 +14,7 @@
 // [N][K] so that a wave reads one output column as a contiguous, 16-B-per-lane stream).
 // Sampling: temperature <= 0 -> argmax, lowest index on ties (tf.argmax); otherwise Gumbel-max over
 // logits/temperature == a draw from softmax(logits/temperature) (tf.random.categorical, cli.py:671-673).
-#include "model.h"
+#include "../model.h"
 
 struct DecState {        // device-resident loop state
     int pos;             // position id of the token about to be consumed
@@ -42,13 +42,14 @@ struct DecodeState {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int mode = 0;
+    bool v1 = false;            // COMPOSER_DECODE_V1=1: first-generation per-token kernels
     float temperature = 0.f;
     uint64_t seed = 0;
     int produced = 0, returned = 0, cap = 0, pos = 0;
     bool begun = false;
     bool built = false;                 // buffers allocated, chain captured (reused by later cmp_decode_begin calls)
     int64_t weights_version = -1;       // cmp_model::param_version the transposed decode weights were made from
-    bool graph_on = false;
+    bool graph_is_v1 = false, graph_on = false;
 };
 
 void decode_state_free(DecodeState* d) {
@@ -83,6 +84,18 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     }
 }
 
+#ifdef COMPOSER_EXPERIMENTS      // first-generation decode kernels (COMPOSER_DECODE_V1=1 in an experiments build): K cache [H][W][D]
+// K/V of the prompt from the prefill's c_attn output [P][3E] (activation dtype) into the cache [H][W][D]
+template <typename T>
+__global__ void cache_fill_kernel(const T* __restrict__ qkv, float* __restrict__ kc, float* __restrict__ vc, int P, int E,
+                                  int H, int D, int W) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * E) return;
+    int t = i / E, e = i % E, h = e / D, d = e % D;
+    kc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + E + e]);
+    vc[((int64_t)h * W + t) * D + d] = to_f32<T>(qkv[(int64_t)t * 3 * E + 2 * E + e]);
+}
+#endif
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -212,6 +225,159 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
     }
 }
 
+#ifdef COMPOSER_EXPERIMENTS      // first-generation attention and sampler kernels
+// Split-key single-query attention: grid (H, ATT_SPLITS).  Workgroup (h, s) owns keys [s*chunk, (s+1)*chunk) of head h
+// (chunk = W/ATT_SPLITS); the one that owns position `pos` appends this token's k,v to the cache.  Scores: 16 lanes
+// cooperate on one key (16-byte coalesced reads of the [W][D] cache rows, D <= 64... 128 via two passes), 4 keys per
+// wave-instruction.  Output: unnormalised o[D], max, sum per (h, s); the next kernel (c_proj GEMV, IN=2) combines them.
+__global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ qkv, float* __restrict__ kc,
+                                                       float* __restrict__ vc, float* __restrict__ part,
+                                                       const DecState* __restrict__ st, int E, int D, int W, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // q[D] | red[8] | scores[cap] | opart[256]
+    const int cap = (W + ATT_SPLITS - 1) / ATT_SPLITS + 4;
+    float* qs = sm;
+    float* red = sm + D;
+    float* sc = red + 8;
+    float* opart = sc + cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.x, sp = blockIdx.y;
+    const int pos = st->pos;
+    // the pos+1 live keys are split evenly (multiples of 4) over the ATT_SPLITS workgroups of this head
+    const int chunk = ((pos + 1 + ATT_SPLITS - 1) / ATT_SPLITS + 3) & ~3;
+    const int j0 = sp * chunk, j1 = min(pos + 1, j0 + chunk);       // keys [j0, j1) of this split (may be empty)
+    float* kh = kc + (int64_t)h * W * D;
+    float* vh = vc + (int64_t)h * W * D;
+    float* out = part + ((size_t)h * ATT_SPLITS + sp) * (D + 2);
+    if (tid < D) {
+        qs[tid] = qkv[h * D + tid];
+        if (pos >= j0 && pos < j1) {
+            kh[(int64_t)pos * D + tid] = qkv[E + h * D + tid];
+            vh[(int64_t)pos * D + tid] = qkv[2 * E + h * D + tid];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int nk = j1 - j0;
+    if (nk <= 0) {
+        if (tid < D) out[tid] = 0.f;
+        if (tid == 0) { out[D] = -INFINITY; out[D + 1] = 0.f; }
+        return;
+    }
+    // scores: LPK lanes per key, each lane owns 4 consecutive d; 8 keys in flight per lane group
+    const int LPK = D / 4;                       // 4, 8, 16 or 32 lanes per key
+    const int kpw = 64 / LPK;                    // keys per wave-instruction
+    const int c = lane % LPK, kk = lane / LPK;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + 4 * c);
+    float mx = -INFINITY;
+    const int stride = 4 * kpw;
+    for (int jb = wave * kpw + kk; jb < nk; jb += 8 * stride) {
+        f32x4 kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * stride;
+            kv[u] = (j < nk) ? *reinterpret_cast<const f32x4*>(kh + (int64_t)(j0 + j) * D + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * stride;
+            float a = qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3];
+            for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o);
+            a *= scale;
+            if (j < nk) {
+                if (c == 0) sc[j] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+    }
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int j = tid; j < nk; j += 256) {
+        float p = expf(sc[j] - mx);
+        sc[j] = p;
+        s += p;
+    }
+    s = block_sum(s, red);
+    __syncthreads();
+    const int groups = 256 / D;
+    const int g = tid / D, dd = tid % D;
+    float o = 0.f;
+    for (int jb = g; jb < nk; jb += 8 * groups) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * groups;
+            vv[u] = (j < nk) ? vh[(int64_t)(j0 + j) * D + dd] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * groups;
+            if (j < nk) o += sc[j] * vv[u];
+        }
+    }
+    opart[tid] = o;
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int gg = 0; gg < groups; gg++) t += opart[gg * D + tid];
+        out[tid] = t;
+    }
+    if (tid == 0) { out[D] = mx; out[D + 1] = s; }
+}
+
+// choose the next id from logits[V]; record it; build the next input embedding x = wte[id] + wpe[pos']
+__global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict__ logits, int ldz_row_off, int V,
+                                                         DecState* __restrict__ st,
+                                                         int32_t* __restrict__ ids, const float* __restrict__ wte,
+                                                         const float* __restrict__ wpe, float* __restrict__ x, int E,
+                                                         int first) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    __shared__ int chosen;
+    const int tid = threadIdx.x;
+    const float* z = logits + ldz_row_off;
+    const unsigned ctr = st->rng;
+    const float temperature = st->temperature;
+    const unsigned seed = st->seed;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        float v = z[c];
+        if (temperature > 0.f) {
+            unsigned hsh = drop_hash(seed, 0xC0FFEEu + ctr, (uint64_t)c);
+            // 23 bits + 0.5: every value is exact in fp32 and strictly inside (0,1) (24 bits + 0.5 rounds up to 1.0 for the
+            // top value: -log(-log(1)) = +inf, one token in ~43 000 would ignore its logit)
+            float u = ((float)(hsh >> 9) + 0.5f) * (1.0f / 8388608.0f);
+            v = v / temperature - logf(-logf(u));
+        }
+        if (v > best) { best = v; arg = c; }
+    }
+    bv[tid] = best;
+    bi[tid] = arg;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            float ov = bv[tid + s];
+            int oi = bi[tid + s];
+            if (ov > bv[tid] || (ov == bv[tid] && oi < bi[tid])) { bv[tid] = ov; bi[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int id = min(max(bi[0], 0), V - 1);         // all-NaN logits leave the sentinel index: never address outside wte
+        chosen = id;
+        int n = st->produced;
+        if (n < st->cap) ids[n] = id;
+        st->produced = n + 1;
+        st->rng = ctr + 1;
+        st->token = id;
+        if (!first) st->pos = st->advance ? st->pos + 1 : 0;
+    }
+    __syncthreads();
+    const int id = chosen;
+    int pos = st->pos;             // written by tid 0 above, visible after the barrier
+    if (pos >= st->W) pos = st->W - 1;   // host refuses to step past the table; never index outside it
+    for (int e = tid; e < E; e += 256) x[e] = wte[(int64_t)id * E + e] + wpe[(int64_t)pos * E + e];
+}
+#endif  // COMPOSER_EXPERIMENTS
 
 
 // =================================================================================================
@@ -224,7 +390,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(const float* __restrict__
 //   * attention: the K cache is stored [H][D/4][W][4] so that TWO lanes own a key (one DPP add per score instead of a
 //     16-lane shuffle tree); each wave runs its own online softmax over its keys and the four waves meet at ONE barrier;
 //     the current token's k/v come from the c_attn output instead of a write -> barrier -> read through the cache.
-// (The first-generation kernels live in experiments/decode_lab.hip.)
+// In an experiments build (-DCOMPOSER_EXPERIMENTS) COMPOSER_DECODE_V1=1 selects the first-generation kernels above.
 // =================================================================================================
 #define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 #define DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
@@ -271,7 +437,11 @@ __global__ __launch_bounds__(256) void dec_gemv2_kernel(const float* __restrict_
         for (int i = 0; i < KI; i++) {
             const int k = (lane + 64 * i) * 4;
             // streamed once per token by one wave: non-temporal (MI355X_MICROARCH "nt-weights": shorter issue-to-landed time)
+#ifdef DEC_HALF_W      // timing experiment only (wrong results): what a half-size (bf16) weight stream would cost
+            wv[c][i] = (k < K && (i & 1) == 0) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + k / 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
             wv[c][i] = (k < K) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + k)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
         }
     }
     if (IN == 2) {
@@ -581,7 +751,11 @@ static int launch_gemv2(hipStream_t s, int act, int in_mode, const float* x, con
     CMP_REQUIRE(K % 4 == 0, "decode gemv: K=%d must be a multiple of 4", K);
     // CW = 2 columns per wave for the wide outputs of the narrow-K launches; 4, 2 or 1 waves per workgroup so that the narrow
     // outputs still give every CU a workgroup
+#ifdef DEC_NO_CW2
+    const int cw = 1;
+#else
     const int cw = (K <= 512 && N >= 1024) ? 2 : 1;
+#endif
     const int waves = cdiv(N, cw);
     int block = 256;
     while (block > 64 && cdiv(waves, block / 64) < 256) block >>= 1;
@@ -610,6 +784,47 @@ static int launch_attn2(hipStream_t s, cmp_model* m, DecodeState* d, const DecLa
 
 static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
     hipStream_t s = m->ctx->stream;
+    // COMPOSER_DECODE_DIAG_SKIP (experiments builds only; timing diagnosis -- the ids are wrong): bit 0 LN1+c_attn, 1 attention,
+    // 2 c_proj, 3 LN2+c_fc, 4 mlp c_proj, 5 logits, 6 sampler are left out of the captured chain
+    int skip = 0;
+#ifdef COMPOSER_EXPERIMENTS
+    { const char* e = getenv("COMPOSER_DECODE_DIAG_SKIP"); if (e) skip = atoi(e); }
+#endif
+    const int E = m->E, Ea = m->Ea, L = m->L;
+    const bool ln = m->cfg.use_layer_norm != 0;
+    const float eps = m->cfg.ln_eps;
+    const float scale = m->cfg.scale_attention ? 1.0f / sqrtf((float)m->Dl) : 1.0f;
+    for (int i = 0; i < L; i++) {
+        const LayerOff& o = m->lo[i];
+#ifdef DEC_ALIAS_L0     // timing experiment only (wrong results): every block reads block 0's weights, which then stay in L2
+        const DecLayerW w = [&] { DecLayerW t = d->lw[0]; t.kc = d->lw[i].kc; t.vc = d->lw[i].vc; return t; }();
+#else
+        const DecLayerW& w = d->lw[i];
+#endif
+        if (!(skip & 1)) CHECK_RC(launch_gemv2(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
+                              d->qkv, d->u, E, 3 * Ea, m->D));
+        if (!(skip & 2)) CHECK_RC(launch_attn2(s, m, d, w, scale));
+        if (!(skip & 4)) CHECK_RC(launch_gemv2(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, Ea, E, m->D));
+        if (!(skip & 8)) CHECK_RC(launch_gemv2(s, 1, ln ? 1 : 0, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
+                              nullptr, E, 4 * E, m->D));
+        if (!(skip & 16)) CHECK_RC(launch_gemv2(s, 0, 0, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E, m->D));
+    }
+    if (!(skip & 32)) CHECK_RC(launch_gemv2(s, 0, 1, d->x, m->P + m->off_lnf_g, m->P + m->off_lnf_b, eps, m->P + m->off_wte, nullptr, nullptr,
+                          d->logits, nullptr, E, m->V, m->D));
+    if (!(skip & 64)) dec_sample2_kernel<<<1, 256, 0, s>>>(d->logits, 0, m->V, d->st, d->ids, m->P + m->off_wte,
+                                         m->P + m->off_wpe, d->x, E, 0);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+
+// one token: consumes d->x (embedding of st->token at st->pos), produces the next id and the next d->x
+static int enqueue_token_step(cmp_model* m, DecodeState* d) {
+    if (!d->v1) return enqueue_token_step2(m, d);
+#ifndef COMPOSER_EXPERIMENTS
+    cmp_set_error("decode: the first-generation kernels exist only in an experiments build");
+    return CMP_ERR_STATE;
+#else
+    hipStream_t s = m->ctx->stream;
     const int E = m->E, Ea = m->Ea, L = m->L;
     const bool ln = m->cfg.use_layer_norm != 0;
     const float eps = m->cfg.ln_eps;
@@ -617,24 +832,24 @@ static int enqueue_token_step2(cmp_model* m, DecodeState* d) {
     for (int i = 0; i < L; i++) {
         const LayerOff& o = m->lo[i];
         const DecLayerW& w = d->lw[i];
-        CHECK_RC(launch_gemv2(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
-                              d->qkv, d->u, E, 3 * Ea, m->D));
-        CHECK_RC(launch_attn2(s, m, d, w, scale));
-        CHECK_RC(launch_gemv2(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, Ea, E, m->D));
-        CHECK_RC(launch_gemv2(s, 1, ln ? 1 : 0, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
-                              nullptr, E, 4 * E, m->D));
-        CHECK_RC(launch_gemv2(s, 0, 0, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E, m->D));
+        CHECK_RC(launch_gemv(s, 0, ln ? 1 : 0, d->x, m->P + o.ln1_g, m->P + o.ln1_b, eps, w.attn_wT, m->P + o.attn_b, nullptr,
+                             d->qkv, d->u, E, 3 * Ea, m->D));
+        size_t smem = (size_t)(m->D + 8 + (m->W + ATT_SPLITS - 1) / ATT_SPLITS + 4 + 256) * 4;
+        dec_attn_kernel<<<dim3(m->H, ATT_SPLITS), 256, smem, s>>>(d->qkv, w.kc, w.vc, d->att, d->st, Ea, m->D, m->W, scale);
+        KERNEL_CHECK();
+        CHECK_RC(launch_gemv(s, 0, 2, d->att, nullptr, nullptr, eps, w.proj_wT, m->P + o.proj_b, d->u, d->r, nullptr, Ea, E, m->D));
+        CHECK_RC(launch_gemv(s, 1, ln ? 1 : 0, d->r, m->P + o.ln2_g, m->P + o.ln2_b, eps, w.fc_wT, m->P + o.fc_b, nullptr, d->g,
+                             nullptr, E, 4 * E, m->D));
+        CHECK_RC(launch_gemv(s, 0, 0, d->g, nullptr, nullptr, eps, w.pr_wT, m->P + o.pr_b, d->r, d->x, nullptr, 4 * E, E, m->D));
     }
-    CHECK_RC(launch_gemv2(s, 0, 1, d->x, m->P + m->off_lnf_g, m->P + m->off_lnf_b, eps, m->P + m->off_wte, nullptr, nullptr,
-                          d->logits, nullptr, E, m->V, m->D));
-    dec_sample2_kernel<<<1, 256, 0, s>>>(d->logits, 0, m->V, d->st, d->ids, m->P + m->off_wte,
-                                         m->P + m->off_wpe, d->x, E, 0);
+    CHECK_RC(launch_gemv(s, 0, 1, d->x, m->P + m->off_lnf_g, m->P + m->off_lnf_b, eps, m->P + m->off_wte, nullptr, nullptr,
+                         d->logits, nullptr, E, m->V, m->D));
+    dec_sample_kernel<<<1, 256, 0, s>>>(d->logits, 0, m->V, d->st, d->ids, m->P + m->off_wte,
+                                        m->P + m->off_wpe, d->x, E, 0);
     KERNEL_CHECK();
     return CMP_OK;
+#endif
 }
-
-// one token: consumes d->x (embedding of st->token at st->pos), produces the next id and the next d->x
-static int enqueue_token_step(cmp_model* m, DecodeState* d) { return enqueue_token_step2(m, d); }
 
 extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int mode, float temperature, uint64_t seed) {
     CMP_REQUIRE(m && prompt && P > 0, "decode_begin: prompt must hold at least one id");
@@ -649,6 +864,11 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     // transposes, capture + instantiate: 6 % of a 1024-token generate) what is left is the prefill.  The transposes are
     // redone when a parameter has changed since (cmp_model::param_version); the chain is re-captured only when the kernel
     // generation or the graph switch changes (temperature, seed and mode live in the device-side state).
+#ifdef COMPOSER_EXPERIMENTS
+    const bool v1 = [] { const char* e = getenv("COMPOSER_DECODE_V1"); return e && e[0] == '1'; }();
+#else
+    const bool v1 = false;
+#endif
     const bool graph_on = [] { const char* e = getenv("COMPOSER_NO_GRAPH"); return !(e && e[0] == '1'); }();
     DecodeState* d = m->dec;
     if (d && !d->built) {                       // an earlier call failed part-way (an allocation, the capture): start over
@@ -656,7 +876,7 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
         decode_state_free(d);
         m->dec = d = nullptr;
     }
-    if (d && d->built && (d->graph_on != graph_on)) {
+    if (d && d->built && (d->graph_is_v1 != v1 || d->graph_on != graph_on)) {
         HIP_CHECK(hipStreamSynchronize(s));
         decode_state_free(d);
         m->dec = d = nullptr;
@@ -667,6 +887,7 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     }
     d->begun = false;
     d->mode = mode;
+    d->v1 = v1;
     d->temperature = temperature;
     d->seed = seed;
     d->cap = 1 << 16;
@@ -715,6 +936,14 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     if (mode == CMP_DECODE_KV) {
         for (int i = 0; i < L; i++) {
             int grid = cdiv(P * Ea, 256);
+#ifdef COMPOSER_EXPERIMENTS
+            if (d->v1) {
+                if (m->dtype == CMP_BF16)
+                    cache_fill_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
+                else
+                    cache_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
+            } else
+#endif
             {
                 if (m->dtype == CMP_BF16)
                     cache_fill2_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)m->act[i].qkv, d->lw[i].kc, d->lw[i].vc, P, Ea, m->H, m->D, W);
@@ -736,6 +965,10 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
     h.seed = (unsigned)seed;
     HIP_CHECK(hipMemcpyAsync(d->st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     // first id from the last prompt row (cli.py:673 `[-1, 0]`)
+#ifdef COMPOSER_EXPERIMENTS
+    if (d->v1) dec_sample_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, d->st, d->ids, m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
+    else
+#endif
     dec_sample2_kernel<<<1, 256, 0, s>>>(m->logits, (P - 1) * m->ldz, m->V, d->st, d->ids, m->P + m->off_wte, m->P + m->off_wpe, d->x, E, 1);
     KERNEL_CHECK();
     HIP_CHECK(hipStreamSynchronize(s));
@@ -754,6 +987,7 @@ extern "C" int cmp_decode_begin(cmp_model* m, const int32_t* prompt, int P, int 
             d->graph = g;
             HIP_CHECK(hipGraphInstantiate(&d->exec, g, nullptr, nullptr, 0));
         }
+        d->graph_is_v1 = v1;
         d->graph_on = graph_on;
         d->built = true;
     }

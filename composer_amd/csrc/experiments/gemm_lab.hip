@@ -13,7 +13,7 @@
 //   contraction-slow ones : LDS image [64 k][128 cols] (256-B rows, chunk XOR 2*((k&3)|((k>>3)&1)<<2)),
 //                           fragments by two ds_read_b64_tr_b16 (hardware transpose, conflict-free).
 // fp32 path (parity mode): v_mfma_f32_16x16x4_f32 = exact fp32 fma chains, 64x64x16 tile.
-#include "common.h"
+#include "../common.h"
 #include <vector>
 #include <mutex>
 
@@ -1135,6 +1135,10 @@ struct ItemPuller {
 //   * same LDS images / swizzles / direct-to-LDS staging / range-checked descriptors as the 128^2 fast path.
 // LDS: 2 stages x (A 32 KiB + B 32 KiB) = 128 KiB.
 // =================================================================================================
+#if !defined(COMPOSER_EXPERIMENTS) || !defined(GEMM_DIAG)      // measurement ladders exist in experiments builds only
+#undef GEMM_DIAG
+#define GEMM_DIAG 0
+#endif
 #define H_BM 256
 #define H_BN 256
 #define H_IMG (256 * 64 * 2)
@@ -1254,17 +1258,51 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();      // stage 0 of this item has landed (vmcnt(0) rides on the barrier); previous epilogue left stage 1
+        bf16x8 diag_a[2][2][4], diag_b[2][4];       // GEMM_DIAG 2 / 4 only
         if (!run) kt1 = kt0;                        // (nothing of the scheduler inside the k-loop, see ItemPuller)
+#ifdef GEMM_EARLY_SLAB
+        // Static striding, an even number of k-steps (the last one computes out of stage 1, stage 0 is free by then): the NEXT
+        // item's first k-slab is issued at the top of this item's LAST k-step, like any other stage, instead of behind the loop.
+        // Memory reads are delivered in issue order, so with the slab issued just in front of the epilogue every operand load of
+        // the epilogue (residual, gelu' input, bias) waited until the slab had landed; a k-step earlier it has landed by then.
+        // Not for the fold kinds: their LDS-DMA image must be requested in front of the slab and lives in stage 1.
+        constexpr bool EARLY_OK = SWAP && !((LNM & 1) != 0 && EPI != EPI_RESID && EPI != EPI_GENERIC);
+        const bool early = EARLY_OK && !pl.ctr && run && ((kt1 - kt0) & 1) == 0 && kt1 > kt0 && item + (int)gridDim.x < nitems;
+        int m0n = 0, n0n = 0, kt0n = 0, kt1n = 0;
+        __amdgpu_buffer_rsrc_t ran = ra, rbn = rb;
+        if (early) {
+            item_coords(item + gridDim.x, m0n, n0n, kt0n, kt1n);
+            ran = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0n);
+            rbn = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0n);
+        }
+#else
         constexpr bool early = false;
+#endif
         for (int kt = kt0; kt < kt1; kt++) {
             const int st = (kt - kt0) & 1;
             const char* ia = smem + st * 2 * H_IMG;
             const char* ib = ia + H_IMG;
-            if (kt + 1 < kt1) {
+#ifdef GEMM_EARLY_SLAB
+            if (early && kt + 1 == kt1) {
+                glds_tile256<A_KM, A_AUX>(ran, smem, lda * 2, kt0n * G_BK, wave, lane);
+                glds_tile256<B_KM>(rbn, smem + H_IMG, ldb * 2, kt0n * G_BK, wave, lane);
+            }
+#endif
+            // GEMM_DIAG (measurement builds only -- the results are wrong; tools/ubench/gemm_latency_probe.py):
+            // 1 = no MFMA (fragment reads kept alive), 2 = no LDS fragment reads (the first step's fragments reused),
+            // 3 = no DMA inside the k-loop, 4 = neither reads nor DMA (MFMA + barrier only), 5 = as 1 with TWO stage loads per step
+            if (kt + 1 < kt1 && GEMM_DIAG != 3 && GEMM_DIAG != 4) {
                 char* na = smem + (st ^ 1) * 2 * H_IMG;
                 glds_tile256<A_KM, A_AUX>(ra, na, lda * 2, (kt + 1) * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, (kt + 1) * G_BK, wave, lane);
+#if GEMM_DIAG == 5
+                // bandwidth probe: a second, different slab per step into the same buffer -> 128 KiB in flight per CU
+                const int k2 = (kt + 1 + (kt1 - kt0) / 2) % (kt1 - kt0) + kt0;
+                glds_tile256<A_KM, A_AUX>(ra, na, lda * 2, k2 * G_BK, wave, lane);
+                glds_tile256<B_KM>(rb, na + H_IMG, ldb * 2, k2 * G_BK, wave, lane);
+#endif
             }
+#if GEMM_DIAG == 0
             {
                 // The k-step as an explicit software pipeline, its order pinned: the fragments of MFMA group g+1 are requested in
                 // front of group g's sixteen MFMAs.  hipcc finds this order by itself in some surroundings and not in others (the
@@ -1308,6 +1346,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
                 __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             }
+#else
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 fb[4];
+                const bool rd = (GEMM_DIAG != 2 && GEMM_DIAG != 4) || kt == kt0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) fb[j] = rd ? h_frag<B_KM>(ib, wn * 4 + j, ks, lane) : diag_b[ks][j];
+                if (GEMM_DIAG == 2 || GEMM_DIAG == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) diag_b[ks][j] = fb[j];
+                }
+#pragma unroll
+                for (int ih = 0; ih < 2; ih++) {
+                    bf16x8 fa[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) fa[i] = rd ? h_frag<A_KM>(ia, wm * 8 + ih * 4 + i, ks, lane) : diag_a[ks][ih][i];
+                    if (GEMM_DIAG == 2 || GEMM_DIAG == 4) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) diag_a[ks][ih][i] = fa[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+#if GEMM_DIAG == 1 || GEMM_DIAG == 5
+                            asm volatile("" ::"v"(fa[i]), "v"(fb[j]));
+#else
+                            if (SWAP) acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih * 4 + i][j], 0, 0, 0);
+                            else acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[ih * 4 + i][j], 0, 0, 0);
+#endif
+                        }
+                }
+            }
+#endif
             __syncthreads();
         }
         if (pl.ctr) {                               // the item claimed a whole item ago, through the slot (one more barrier per item)
@@ -1679,7 +1751,11 @@ __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __res
                 stamp(11);
                 __builtin_amdgcn_s_barrier();
                 stamp(12);
-                do_issue = t + AHEAD < n;
+#if !defined(COMPOSER_EXPERIMENTS) || !defined(P4_DIAG)      // measurement ladders exist in experiments builds only
+#undef P4_DIAG
+#define P4_DIAG 0
+#endif
+                do_issue = t + AHEAD < n && P4_DIAG != 3;       // P4_DIAG (measurement builds, wrong results): 1 no MFMA, 3 no DMA in the k-loop
                 stamp(13);
                 if (t + 1 < n) {
 #pragma unroll
@@ -1705,8 +1781,12 @@ __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __res
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
+#if P4_DIAG == 1
+                    asm volatile("" ::"v"(fa[i]), "v"(fb[j]));
+#else
                     if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#endif
                 }
             }
             if (t + 1 < n) {
@@ -2130,14 +2210,6 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
     put(&K, sizeof(K));
     put(&G, sizeof(G));
     if (key != g->key) {
-        {   // building a table synchronises the stream: not inside a capture (cmp_train_step_launches on a model that has not stepped yet)
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-                cmp_set_error("grouped weight gradients: the item table of these shapes does not exist yet and cannot be built inside a stream "
-                              "capture -- run one train step of this shape first");
-                return CMP_ERR_STATE;
-            }
-        }
         struct Seg { int prob, m0, n0; };
         std::vector<Seg> tiles;
         for (int i = 0; i < nprob; i++)

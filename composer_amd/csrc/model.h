@@ -183,6 +183,8 @@ struct cmp_model {
     int dp_msgs_step = 0;              // all-reduce calls of the last step
     int dp_buckets_updated = 0;        // buckets of the step being enqueued whose Adam update is already on the communication stream
     bool poisoned = false;             // a data-parallel step failed after some of them: parameters partially stepped (train steps refuse)
+    std::vector<char> reload_seen;     // while poisoned: which parameters cmp_param_set has replaced since (all of them clears the flag)
+    int ln_fused_mode = -1;            // COMPOSER_LN_FUSED as read when the model was created (-1 unset, 0 off, 2 training passes too)
     DecodeState* dec = nullptr;
     int gemm_role = -1;                // profiler class of the GEMMs being enqueued (0 while the forward pass is)
 

@@ -298,6 +298,10 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     HIP_CHECK(hipSetDevice(ctx->device));
     cmp_model* m = new cmp_model();
     m->ctx = ctx;
+    {   // COMPOSER_LN_FUSED is read ONCE per model, here (tests switch it between models): 0 off, 2 training passes too
+        const char* e = getenv("COMPOSER_LN_FUSED");
+        m->ln_fused_mode = e ? atoi(e) : -1;
+    }
     // a failure part-way (an allocation, an event) must not leave the buffers allocated so far behind
     const int rc = model_create_fill(m, ctx, cfg, V, E, W, L, H, D, Dl);
     if (rc != CMP_OK) { cmp_model_destroy(m); return rc; }
@@ -508,7 +512,16 @@ extern "C" int cmp_param_set(cmp_model* m, const char* name, int kind, const flo
         HIP_CHECK(hipMemcpyAsync(b + p.offset, host, (size_t)numel * 4, hipMemcpyHostToDevice, m->ctx->stream));
         HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     }
-    if (kind == 0) { m->param_version += 1; m->poisoned = false; }      // (a checkpoint reload goes through here for every tensor)
+    if (kind == 0) {
+        m->param_version += 1;
+        if (m->poisoned) {      // a checkpoint reload goes through here for every tensor: the flag falls when ALL of them have been set
+            if (m->reload_seen.size() != m->params.size()) m->reload_seen.assign(m->params.size(), 0);
+            m->reload_seen[it->second] = 1;
+            bool all = true;
+            for (char c : m->reload_seen) all = all && c;
+            if (all) { m->poisoned = false; m->reload_seen.clear(); }
+        }
+    }
     if (kind == 0 && m->S) {
         int64_t n8 = (p.store + 7) / 8 * 8;
         CHECK_RC(launch_cast_bf16(m->ctx->stream, m->P + p.offset, m->S + p.offset, n8));
@@ -686,12 +699,8 @@ static int refresh_transposed_weights(cmp_model* m, bool fold) {
 // backward kernels of a block write u / n instead of the forward kernels, and the fold GEMMs read a colder A operand than the
 // one a LayerNorm kernel has just written), so training passes take it only when COMPOSER_LN_FUSED=2 asks for it (tests).
 static bool ln_fused_ok(const cmp_model* m, int M, int past_len, bool training) {
-#ifdef COMPOSER_WGRAD_UNGROUPED
-    return false;
-#endif
-    const char* e = getenv("COMPOSER_LN_FUSED");
-    if (e && e[0] == '0') return false;
-    if (training && !(e && e[0] == '2')) return false;
+    if (m->ln_fused_mode == 0) return false;
+    if (training && m->ln_fused_mode != 2) return false;
     if (!m->cfg.use_layer_norm || m->dtype != CMP_BF16 || m->slab || past_len) return false;
     if (m->Ea != m->E || m->E % 256 || m->E < 512 || m->E > 768 || !m->act[0].ln1_part) return false;   // 2 or 3 segments (the fold images' LDS)
     if (M % 256 || (int64_t)(M / 256) * (m->E / 256) < 192) return false;      // gemm_run's `big`: the N = E GEMMs too
@@ -868,8 +877,10 @@ int model_forward(cmp_model* m, const int32_t* x_dev, int B, int T, bool trainin
         LnEpi l;
         l.in_part = m->lnf_part; l.np = E / 256; l.eps = m->cfg.ln_eps; l.cs = m->lnf_fold;
         m->hf_valid = false;
+        // (CMP_GEMM_TILE256: the fold epilogue exists on the persistent 256x256 kernel only, and [M, V] has fewer tiles than the
+        //  blocks' [M, E] launches that ln_fused_ok sized the path by -- E = 768, V = 390 at 16 384 tokens: 192 against 128)
         CHECK_RC(gemm(m, 0, 1, M, m->V, E, m->xs[m->L], E, m->wte_lnf, E, m->logits, m->ldz, m->lnf_fold + m->lnf_npad, 0, nullptr, 0, nullptr,
-                      0, 1, 1, 0.f, 0, 0, nullptr, &l));
+                      0, 1, 1, 0.f, 0, CMP_GEMM_TILE256, nullptr, &l));
         return CMP_OK;
     }
     CHECK_RC(cmp_k_layernorm_fwd(s, m->xs[m->L], m->P + m->off_lnf_g, m->P + m->off_lnf_b, m->hf, m->lnf_mean, m->lnf_rstd, M,
@@ -941,14 +952,10 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     {
         // few output tiles (390 x 512 = 4 of 256x256): on the 128x128 kernel the launch is 768 workgroups of a 48th of the tokens each
         // (1.5 rounds, 48 MB of atomics); on the persistent 256x256 deep-pipeline kernel one item per CU
-#ifdef COMPOSER_TIED_WGRAD_OLD
-        const int tsplit = std::max(2, wgrad_splits(M, V, E)), tflags = 0;
-#else
         const int t256 = cdiv(V, 256) * cdiv(E, 256);
         const bool p4 = dt == CMP_BF16 && t256 <= 64 && M >= 65536 && M % 32 == 0;       // (at 32 768 tokens the two forms tie)
         const int tsplit = p4 ? std::max(2, std::min(256 / t256, M / 1024)) : std::max(2, wgrad_splits(M, V, E));
         const int tflags = p4 ? CMP_GEMM_P4 : 0;
-#endif
         CHECK_RC(gemm(m, 1, 0, V, E, M, m->dlogits, m->ldz, m->hf, E, m->G + m->off_wte, E, nullptr, 0, nullptr, 0, nullptr, 0, 1,
                       tsplit, 0.f, 0, tflags));
     }
@@ -972,11 +979,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     // (non-deterministic) split-K form they go out as ONE grouped launch behind the block's attention backward (gemm.hip:
     // gemm_wgrad_group_kernel) -- a quarter of the f32-atomic traffic of four split-K launches, equal k-steps per workgroup.
     // Until then both masked gradient copies of the block stay live: the MLP branch's in dmask, the attention branch's in dmask2.
-#ifdef COMPOSER_WGRAD_UNGROUPED
-    const bool grouped = false;
-#else
     const bool grouped = ln && dt == CMP_BF16 && !m->slab;
-#endif
     CMP_REQUIRE(!fused || grouped, "backward: the fused block path needs the grouped weight-gradient order");
     if (grouped && (int)m->wgrad_groups.size() != m->L) m->wgrad_groups.resize(m->L);
     for (int i = m->L - 1; i >= 0; i--) {
@@ -1157,6 +1160,56 @@ extern "C" int cmp_dp_stats(cmp_model* m, int reset, int64_t* steps, double* exp
     return CMP_OK;
 }
 
+// Which RCCL this process is running on (ncclGetVersion of the library the dynamic linker bound: with torch imported first that is
+// torch's bundled librccl, otherwise /opt/rocm's -- composer_amd/_lib.py reports the path): code = major * 10000 + minor * 100 + patch.
+extern "C" int cmp_dp_rccl_version(int* version) {
+    CMP_REQUIRE(version, "dp_rccl_version: null");
+    NCCL_CHECK(ncclGetVersion(version));
+    return CMP_OK;
+}
+
+// The gradient exchange of ONE train step alone (bench.py --allreduce-only; the first thing to look at when an 8-GPU run scales badly):
+// the step's own message pattern -- the 3-float metrics message, then the L + 2 gradient buckets in the order the backward pass
+// completes them (ln_f, block L-1 ... block 0, embeddings), each the bucket's own range of G -- issued back to back on the communication
+// stream `reps` times between two events, nothing on the compute stream.  G is zeroed first (sums of zeros stay zero) and is garbage for
+// no one: the next train step zeroes it again.  ms = total time of the reps; bytes / msgs = per repetition.
+extern "C" int cmp_dp_allreduce_pattern(cmp_model* m, int reps, double* ms, int64_t* bytes_per_rep, int* msgs_per_rep) {
+    CMP_REQUIRE(m && reps > 0 && ms, "dp_allreduce_pattern: bad arguments");
+    cmp_ctx* c = m->ctx;
+    CMP_REQUIRE(c->dp_on(), "dp_allreduce_pattern: communicator not initialised");
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemsetAsync(m->G, 0, (size_t)m->total * 4, c->comm_stream));
+    HIP_CHECK(hipMemsetAsync(m->dp_metrics, 0, 16, c->comm_stream));
+    hipEvent_t a = nullptr, b = nullptr;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    int64_t bytes = 0;
+    int msgs = 0, rc = CMP_OK;
+    auto one = [&](float* p, int64_t n) { if (rc == CMP_OK) { rc = dp_allreduce(c, p, (size_t)n); bytes += n * 4; msgs += 1; } };
+    for (int r = -1; r < reps && rc == CMP_OK; r++) {       // r = -1: one untimed repetition (connection set-up, first-use allocations)
+        if (r == 0) { HIP_CHECK(hipEventRecord(a, c->comm_stream)); bytes = 0; msgs = 0; }
+        one(m->dp_metrics, 3);
+        one(m->G + m->off_lnf_g, m->total - m->off_lnf_g);
+        for (int i = m->L - 1; i >= 0; i--) one(m->G + m->lo[i].begin, m->lo[i].end - m->lo[i].begin);
+        one(m->G, m->lo[0].begin);
+    }
+    if (rc == CMP_OK) {
+        HIP_CHECK(hipEventRecord(b, c->comm_stream));
+        HIP_CHECK(hipEventSynchronize(b));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, a, b));
+        *ms = t;
+    } else {
+        (void)hipStreamSynchronize(c->comm_stream);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (bytes_per_rep) *bytes_per_rep = bytes / reps;
+    if (msgs_per_rep) *msgs_per_rep = msgs / reps;
+    return rc;
+}
+
 extern "C" int cmp_model_path_info(cmp_model* m, int* fused, int64_t* wgrad_table_builds) {
     CMP_REQUIRE(m, "model_path_info: null model");
     if (fused) *fused = m->fused_last ? 1 : 0;
@@ -1210,7 +1263,12 @@ static int train_step_enqueue(cmp_model* m, const int32_t* x_dev, const int32_t*
         if (hipEventRecord(m->comm_done, c->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, m->comm_done, 0);
         else (void)hipStreamSynchronize(c->comm_stream);
         (void)hipGetLastError();
-        if (m->dp_buckets_updated > 0) m->poisoned = true;
+        if (m->dp_buckets_updated > 0) {
+            m->poisoned = true;
+            m->param_version += 1;         // some buckets moved: transposed / folded weight copies and the decode weights are stale
+            m->st_state = 0;
+            m->reload_seen.assign(m->params.size(), 0);
+        }
     }
     return rc;
 }
@@ -1230,8 +1288,11 @@ extern "C" int cmp_train_step_dev(cmp_model* m, const void* x_dev, const void* y
 }
 
 // Diagnostic: how many launches ONE train step of this shape enqueues.  The step is stream-captured (nothing executes), the nodes of
-// the captured graph are counted by type, the graph is dropped and the host-side state the enqueue touched is put back.  Not
-// available once a communicator exists (RCCL calls inside a capture).
+// the captured graph are counted by type, the graph is dropped and the host-side state the enqueue touched is put back (optimizer
+// iteration, parameter / pass generations, what the transposed shadows hold, and the description of the pass whose activations are
+// held: shape, path, whether ln_f's output exists -- cmp_present_get / cmp_hidden_get_at keep answering for the last EXECUTED pass).
+// Needs one executed train step of the same shape first (item tables of the grouped weight gradients).  Not available once a
+// communicator exists (RCCL calls inside a capture).
 extern "C" int cmp_train_step_graph_probe(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others,
                                          int replay_reps, float* replay_ms);
 extern "C" int cmp_train_step_launches(cmp_model* m, const void* x_dev, const void* y_dev, int B, int T, int* kernels, int* others) {
@@ -1246,12 +1307,16 @@ extern "C" int cmp_train_step_graph_probe(cmp_model* m, const void* x_dev, const
     hipStream_t s = m->ctx->stream;
     HIP_CHECK(hipStreamSynchronize(s));
     const int64_t it = m->iterations, pv = m->param_version, gen = m->fwd_gen, stv = m->st_version;
-    const int sts = m->st_state;
+    const int sts = m->st_state, lB = m->lastB, lT = m->lastT, lP = m->last_past;
+    const bool fl = m->fused_last, hv = m->hf_valid;
+    // (precondition: the grouped weight-gradient item tables of this shape exist, i.e. one train step of the shape has EXECUTED --
+    //  building them synchronises the stream, which a capture cannot do; wgrad_group_run says so when it happens)
     HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = train_step_enqueue(m, (const int32_t*)x_dev, (const int32_t*)y_dev, B, T, 0.f);
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(s, &g);
     m->iterations = it; m->param_version = pv; m->fwd_gen = gen; m->st_version = stv; m->st_state = sts;
+    m->lastB = lB; m->lastT = lT; m->last_past = lP; m->fused_last = fl; m->hf_valid = hv;
     if (rc != CMP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIP_CHECK(e);
     size_t n = 0;

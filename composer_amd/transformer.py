@@ -206,6 +206,7 @@ class Transformer:
     def init_data_parallel(self, rank, world_size, unique_id, gemm_cus=None):
         """One rank per GPU; `unique_id` = 128 bytes from rank 0's `new_unique_id()` shared by the launcher.
         gemm_cus: CUs the persistent GEMM kernels may occupy while gradients are all-reduced (None/0 = all 256)."""
+        _lib.check_single_runtime()      # a second RCCL mapped beside the one the library is bound to: fail here, with the paths
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _lib.check(self._lib.cmp_dp_init(self._ctx, int(rank), int(world_size), buf), 'cmp_dp_init')
         if gemm_cus:
@@ -240,6 +241,14 @@ class Transformer:
         a = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
         _lib.check(self._lib.cmp_dp_allreduce_test(self._ctx, a.ctypes.data_as(C.c_void_p), a.size), 'cmp_dp_allreduce_test')
         return a
+
+    def all_reduce_pattern(self, reps=20):
+        """The gradient exchange of one train step alone (cmp_dp_allreduce_pattern): the step's own bucket pattern back to back on the
+        communication stream.  Returns ms per repetition, bytes and messages per repetition.  Collective: every rank calls it."""
+        ms, nbytes, msgs = C.c_double(), C.c_int64(), C.c_int()
+        _lib.check(self._lib.cmp_dp_allreduce_pattern(self._h, int(reps), C.byref(ms), C.byref(nbytes), C.byref(msgs)),
+                   'cmp_dp_allreduce_pattern')
+        return {"ms": ms.value / reps, "bytes": nbytes.value, "messages": msgs.value, "reps": int(reps)}
 
     def dp_stats(self, reset=False):
         """Gradient-exchange telemetry since the last reset (cmp_dp_stats): steps, the communication time per step that the

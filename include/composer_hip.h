@@ -108,6 +108,13 @@ int cmp_dp_set_mask_rank(cmp_ctx* ctx, int rank);
  * behind the backward pass), and the last step's bytes and number of ncclAllReduce calls (L+2 gradient buckets + the 3-float
  * metrics message).  All zeros without a communicator.  Synchronises with the steps it reports. */
 int cmp_dp_stats(cmp_model* m, int reset, int64_t* steps, double* exposed_ms, int64_t* bytes_per_step, int* msgs_per_step);
+/* ncclGetVersion of the RCCL this process is bound to (major * 10000 + minor * 100 + patch); needs no communicator. */
+int cmp_dp_rccl_version(int* version);
+/* The gradient exchange of one train step ALONE: the step's message pattern (3-float metrics message, then the L + 2 gradient buckets
+ * in backward order, each its own range of the gradient buffer) issued back to back on the communication stream, `reps` times between
+ * two HIP events after one untimed repetition; nothing runs on the compute stream.  ms = the reps' total; bytes / messages per
+ * repetition.  The gradient buffer is left zeroed.  Every rank must call it with the same reps (bench.py --allreduce-only). */
+int cmp_dp_allreduce_pattern(cmp_model* m, int reps, double* ms, int64_t* bytes_per_rep, int* msgs_per_rep);
 
 /* ---- model: replaces models.Transformer(...) construction (cli.py:123-132) --------------------- */
 /* Accepted configurations (anything else: CMP_ERR_INVALID with the reason in cmp_last_error): any vocabulary size; embedding_size

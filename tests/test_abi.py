@@ -80,3 +80,23 @@ def test_host_asan_build_runs_the_error_paths_clean():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "asan_probe.py")], capture_output=True, text=True,
                        env=dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0 and "asan probe done" in r.stdout and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
+
+
+def test_the_library_refuses_a_second_gpu_runtime_in_the_process():
+    """Library load order: libcomposer_hip.so loaded BEFORE torch binds to /opt/rocm's runtime, a later `import
+    torch` maps torch's own copies beside it; the binding notices at its next check and names both paths and the fix.  The other
+    order (torch first: this test session, bench.py, the CLI under a launcher) shares one runtime."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from composer_amd import _lib\n"
+            "_lib.load(); assert all(len(v) == 1 for v in _lib.mapped_runtime_libraries().values())\n"
+            "import torch\n"
+            "try:\n"
+            "    _lib.require_gpu()\n"
+            "except _lib.HipLibraryError as e:\n"
+            "    assert 'two copies' in str(e) and 'torch/lib' in str(e) and 'import torch' in str(e); print('REFUSED')\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "REFUSED" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
+    from composer_amd import _lib
+    assert all(len(v) == 1 for v in _lib.mapped_runtime_libraries().values()), _lib.mapped_runtime_libraries()

@@ -13,6 +13,30 @@ from oracle import transformer_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+NEAR_TIE = 1e-3     # logit units: the bound under which the oracle's top-2 margin counts as a tie a last-bit weight difference may flip
+
+
+def assert_greedy_identity(orc, prompt, ids, want, what):
+    """north_star's "bit-exact greedy ids" at the CLI level: the HIP ids equal the oracle's position by position.  The HIP weights after
+    N trained fp32 steps differ from the oracle's in their last bits, so ONE exception is allowed and it is checked, not assumed: at the
+    first mismatch the oracle's own top-2 logit margin (oracle weights, the shared context) must be below NEAR_TIE and the HIP id must
+    be the oracle's runner-up; the comparison stops there (the contexts differ from then on).  Everything before is identical."""
+    assert len(ids) == len(want), (what, ids, want)
+    for i, (a, b) in enumerate(zip(ids, want)):
+        if a == b:
+            continue
+        ctx = np.asarray(list(prompt) + list(want[:i]), dtype=np.int64)[None]
+        z = np.asarray(orc.forward(ctx)[0])[0, -1]
+        order = np.argsort(-z, kind="stable")
+        margin = float(z[order[0]] - z[order[1]])
+        assert int(order[0]) == b, (what, i, "the oracle's own argmax at the shared context is not the id it generated")
+        assert margin < NEAR_TIE and a == int(order[1]), (what, "first mismatch at position %d: HIP %d, oracle %d, oracle top-2 margin %.3e "
+                                                          "(runner-up %d)" % (i, a, b, margin, int(order[1])), ids, want)
+        return i
+    return len(ids)
+
+
+
 def test_c1_train_evaluate_generate(tmp_path):
     from composer_amd import cli, config, dataset as D, checkpoint as ckpt
     root = tmp_path / "data"
@@ -63,12 +87,8 @@ def test_c1_train_evaluate_generate(tmp_path):
                                  "--length", "24", "--temperature", "0", "--decode-mode", mode], catch_exceptions=False)
         assert res.exit_code == 0, res.output
         ids = [int(t) for t in res.output.strip().split("\n")[-1].split(",")]
-        # the HIP weights after 10 fp32 steps differ from the oracle's in the last bits: compare greedy ids where the
-        # oracle's own top-2 margin is not a near-tie
         want = fn(prompt, 24)
-        assert len(ids) == 24
-        agree = sum(a == b for a, b in zip(ids, want))
-        assert agree >= 22, (mode, ids, want)
+        assert_greedy_identity(orc, prompt, ids, want, mode)
         got_ids, _ = D.read_data_file(tmp_path / "out.data")
         assert got_ids.tolist() == prompt + ids
 
@@ -85,7 +105,7 @@ def test_c1_train_evaluate_generate(tmp_path):
     assert res.exit_code == 0, res.output
     ids = [int(t) for t in res.output.strip().split("\n")[-1].split(",")]
     assert len(ids) == 64
-    assert sum(a == b for a, b in zip(ids, orc.generate_kv(want_prompt, 64))) >= 60
+    assert_greedy_identity(orc, want_prompt, ids, orc.generate_kv(want_prompt, 64), "midi prompt")
     # the MIDI file holds exactly the notes of (prompt + generated) events, to half a tick
     events = [D.id_to_event(i, rg, vr) for i in want_prompt + ids]
     direct = nt.NoteSequence.from_events(events)
@@ -198,4 +218,4 @@ def test_cli_with_a_non_default_event_vocabulary_and_head_size(tmp_path):
         assert res.exit_code == 0, res.output
         ids = [int(t) for t in res.output.strip().split("\n")[-1].split(",")]
         want = fn(prompt, 12)
-        assert len(ids) == 12 and sum(a == b for a, b in zip(ids, want)) >= 11, (mode, ids, want)
+        assert_greedy_identity(orc, prompt, ids, want, mode)

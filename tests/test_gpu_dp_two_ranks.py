@@ -11,6 +11,7 @@ test_gpu_model.py then remain the product-side coverage).  When it runs, rank r 
 every step both ranks must hold the parameters of a single-process run on the 2B global batch, and report the same
 (all-reduced) loss."""
 import os
+import socket
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
@@ -20,6 +21,14 @@ from oracle import transformer_oracle as O
 pytestmark = pytest.mark.gpu
 V, E, H, L, W, T, B = 390, 64, 4, 2, 40, 40, 2
 STEPS = 3
+
+
+def _free_port():
+    """A port the kernel has just handed out (bound to port 0, then released): no two rendezvous of a session share one and none
+    collides with another pytest process on the box (the pid-derived ports were reused back to back)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def _worker(rank, world, port, uid_q, out_q):
@@ -55,7 +64,7 @@ def _worker(rank, world, port, uid_q, out_q):
 def test_two_ranks_on_one_gpu_match_the_global_batch():
     ctx = mp.get_context("spawn")
     out_q, uid_q = ctx.Queue(), ctx.Queue()
-    port = 29700 + (os.getpid() % 1000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, uid_q, out_q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -146,7 +155,7 @@ def _xworker(rank, world, port, cfg, out_q):
 def _run_pair(cfg):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
-    port = 29800 + (os.getpid() % 1000)
+    port = _free_port()
     procs = [ctx.Process(target=_xworker, args=(r, 2, port, cfg, out_q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -61,3 +61,27 @@ def test_bench_under_the_launcher_reports_the_gradient_exchange():
     assert comm["ranks"] == 1 and comm["steps"] == 4 and comm["buckets"] == 6 + 2 + 1          # L blocks + ln_f + embeddings, + the metrics message
     assert comm["bytes"] > 4 * 19e6 * 0.9                                                          # every fp32 gradient once
     assert 0.0 <= comm["exposed_ms"] / comm["steps"] < 0.5 * doc["ms_per_step"]
+    # round 6: the line of a launched run is self-diagnosing -- every rank's own step time and exposed communication, and which RCCL /
+    # HIP runtime the process is bound to (one copy of each: _lib.check_single_runtime); stdout holds the JSON line and nothing else
+    assert [r["rank"] for r in doc["ranks"]] == [0] and doc["ranks"][0]["ms_per_step"] > 0 and doc["ranks"][0]["exposed_ms"] is not None
+    rt = doc["runtime"]
+    assert rt["rccl_version"] >= 20000 and os.path.exists(rt["rccl_path"]) and os.path.exists(rt["hip_runtime_path"])
+    assert [l for l in p.stdout.splitlines() if l.strip()] == [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_allreduce_only_times_the_products_bucket_pattern():
+    """`bench.py --allreduce-only`: the gradient exchange of one step alone (cmp_dp_allreduce_pattern) -- 3-float metrics message +
+    ln_f, L blocks and the embeddings as fp32 buckets, every gradient byte once -- under the launcher with one rank (RCCL copies in
+    place; N > 1 needs a multi-GPU node).  The first thing to run when an 8-GPU job scales badly."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--allreduce-only", "--steps", "5"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    doc = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert doc["n_gpus"] == 1 and doc["messages"] == 6 + 2 + 1 and doc["reps"] == 5
+    assert doc["bytes"] == 4 * 19639296 + 12                                  # SURVEY 8: C2 has 19 639 296 parameters
+    assert doc["ms_per_pattern"] > 0 and doc["value"] > 1.0 and doc["runtime"]["rccl_version"] >= 20000

@@ -432,3 +432,31 @@ def test_hidden_states_after_a_pass_that_folded_ln_f():
         os.environ.pop("COMPOSER_LN_FUSED", None)
     assert np.abs(hf - hidden2[L]).max() <= 4e-2 * np.abs(hidden2[L]).max()
     assert np.abs(np.asarray(logits) - np.asarray(logits2)).max() <= 3e-2 * np.abs(np.asarray(logits2)).max()
+
+
+def test_fused_forward_whose_logits_launch_has_fewer_tiles_than_its_block_launches():
+    """E = 768, V = 390 at 16 384 tokens -- the blocks' [M, E] GEMMs have 64 x 3 = 192 tiles of 256 x 256 (the fused
+    path's threshold), the tied-logits GEMM only 64 x 2 = 128: by size it would go to the 128 x 128 kernel, which has no LayerNorm
+    epilogue, and the folded ln_f made the pass fail.  The fold launch now names its kernel; the pass must run, take the fused path and
+    give the unfused path's logits and loss."""
+    E, H, L, T, B = 768, 12, 1, 512, 32
+    params = {k: v.astype(np.float32) for k, v in O.init_params(V, E, T, L, seed=8, stddev=0.05).items()}
+    rng = np.random.default_rng(12)
+    params["ln_f/gamma"] = (1 + 0.2 * rng.normal(size=E)).astype(np.float32)
+    params["ln_f/beta"] = (0.1 * rng.normal(size=E)).astype(np.float32)
+    x, y = O.synthetic_batch(rng, V, B, T)
+    out = {}
+    for mode in ("1", "0"):
+        if mode == "0":
+            os.environ["COMPOSER_LN_FUSED"] = "0"
+        try:
+            m = _model(E, H, L, T, B, 0.0)
+            m.set_weights(params)
+            logits = np.asarray(m(x, training=False)[0]).copy()
+            assert _fused(m)[0] == int(mode)
+            out[mode] = (logits, m.evaluate([(x, y)]))
+            m.close()
+        finally:
+            os.environ.pop("COMPOSER_LN_FUSED", None)
+    assert np.abs(out["1"][0] - out["0"][0]).max() <= 3e-2 * np.abs(out["0"][0]).max()
+    assert abs(out["1"][1][0] - out["0"][1][0]) <= 2e-3 * abs(out["0"][1][0])

@@ -3,7 +3,10 @@
 with the cached objects of the others into composer_amd/lib/<name>.so.  Run the arms in ONE gpurun call (boxes differ by
 up to ~10 %):   COMPOSER_HIP_LIB=composer_amd/lib/<name>.so python tools/kbench.py gemm
     python tools/ab_build.py <name> <source.hip>[,<source2.hip>...] -DFOO [-DBAR ...]
-The experiments build (round-3 attention forwards, first-generation decode kernels, *_DIAG measurement ladders):
+The experiments build (round-3 attention forwards, first-generation decode kernels, *_DIAG measurement ladders): with
+-DCOMPOSER_EXPERIMENTS a source that has a lab copy (composer_amd/csrc/experiments/<name>_lab.hip: the translation unit as it
+stood at the end of round 5, ladders and dead kernels included) is compiled from that copy -- the shipped files hold shipped
+kernels only:
     python tools/ab_build.py experiments attention.hip,decode.hip,gemm.hip -DCOMPOSER_EXPERIMENTS
 """
 import os, subprocess, sys
@@ -16,7 +19,11 @@ def main():
     built = {}
     for src in srcs:
         built[src] = os.path.join(B.OBJ, "ab_%s_%s" % (name, src.replace(".hip", ".o")))
-        subprocess.run([B._hipcc()] + B.flags_for(src) + extra + ["-c", os.path.join(B.CSRC, src), "-o", built[src]], check=True)
+        path = os.path.join(B.CSRC, src)
+        lab = os.path.join(B.CSRC, "experiments", src.replace(".hip", "_lab.hip"))
+        if "-DCOMPOSER_EXPERIMENTS" in extra and os.path.exists(lab):
+            path = lab
+        subprocess.run([B._hipcc()] + B.flags_for(src) + extra + ["-c", path, "-o", built[src]], check=True)
     objs = [built.get(s, os.path.join(B.OBJ, s.replace(".hip", ".o"))) for s in B.SOURCES] + [os.path.join(B.OBJ, "buildkey.o")]
     out = os.path.join(B.LIBDIR, name + ".so")
     subprocess.run([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs +
