@@ -107,7 +107,16 @@ struct GemmExtra {
     bool rev = false;            // persistent 256x256 kernel: walk every XCD group's run of tiles from its end (gemm.hip: item_coords)
     bool dp = false;             // the launch belongs to a data-parallel job: persistent kernels hand their items out dynamically
     SchedWs* sched = nullptr;    // the calling context's item-counter workspace (a cmp_ctx is single-threaded by contract: no lock)
+    struct WgradWs* wws = nullptr;     // grouped weight gradients: the caller's partial-tile workspace selects the last-arriver form
+                                       // (no float atomics: deterministic mode); null: the float-atomic form (default, faster)
 };
+// Partial-tile workspace of the grouped weight-gradient launches of ONE stream (launches on a stream run one after the other, so
+// every decoder block's launch uses the same slots); grown by wgrad_group_run when an item table needs more, freed by the owner.
+struct WgradWs {
+    float* ptr = nullptr;
+    size_t bytes = 0;
+};
+void wgrad_ws_free(WgradWs* w);
 // One launch for several split-K weight gradients that contract over the same K rows (gemm.hip: gemm_wgrad_group_kernel):
 // problem i is C_i[M_i, N_i] (fp32, accumulated into) += A_i^T . B_i with A_i stored [K, M_i] and B_i stored [K, N_i], bf16.
 struct WgradProblem { const void* A; int lda; const void* B; int ldb; float* C; int ldc; int M, N; };
@@ -117,6 +126,10 @@ struct WgradGroup {              // owned by the caller, one per call site whose
     std::string key;             // what that copy was built from (problems, K, workgroup count)
     std::string host;            // the bytes uploaded (kept until the next rebuild: the upload is stream-ordered)
     int nitems = 0, grid = 0;    // nitems == 0 with a key: the cost model chose one launch per problem for these shapes
+    int nslots = 0, ntiles = 0;  // last-arriver form: workspace slots (one per K range of a multi-range tile) and tiles (counters)
+    size_t la_off = 0;           // ... byte offset, in `dev`, of {int cnt[ntiles rounded up to 4], int slot0[ntiles]}
+    bool la = false;             // the table was cut for the last-arriver form (finer K ranges than the float-atomic form affords)
+    bool cnt_dirty = false;      // a launch failed after it may have drawn tickets: the counters are zeroed before the next one
     bool force = false;          // use the grouped launch even where the cost model prefers separate launches (kernel-level tests)
     int64_t rebuilds = 0;        // item tables built so far (a steady train loop builds each block's once: cmp_wgrad_group_rebuilds)
 };

@@ -1510,15 +1510,36 @@ __device__ __forceinline__ bf16x8 p_frag(const char* img, int t16, int lane) {
 // octant (its L2 fetches each operand panel once).  The host builds the item table (gemm_wgrad_group_run).
 #define WG_MAXP 8
 struct WgProb { const bf16_t* A; const bf16_t* B; float* C; int M, N, lda, ldb, ldc, pad; };      // 48 bytes, in device memory
-// item table entry: {problem, m0 | n0 << 16, first k-step, end k-step}; first == end: nothing to do
+// item table entry: {meta, m0 | n0 << 16, first k-step, end k-step}; first == end: nothing to do.
+// meta = problem | index of this K range among the tile's << 4 | K ranges of the tile << 12 | tile << 20
+//
+// Round 6, the last-arriver form (WGLA) -- the grouped launch WITHOUT float atomics, used by COMPOSER_DETERMINISTIC=1 (and by
+// COMPOSER_WGRAD_TAIL=la for A/B runs).  An item whose tile has several K ranges stores its partial tile into its own workspace
+// slot -- register-major ([wave][i][j][lane] as 16-byte vectors: every store instruction one whole KiB), WRITE-THROUGH (sc1: no
+// release fence, the bytes are at the memory side when the wave's vmcnt drains) -- every wave drains, the workgroup meets at a
+// barrier, ONE lane draws a ticket from the tile's counter (relaxed, agent scope), and the workgroup whose ticket is the last one
+// sums the tile's slots in FIXED order (range 0, 1, ...: its own partial is read back like the others, so the sum does not depend
+// on who came last) with sc1 loads (they bypass this CU's L1; cdna_hip_programming.md guideline 16, the counter form with
+// write-through payload) and adds the sum to C with plain loads / stores -- no other workgroup touches that tile of C in this
+// launch.  It then zeroes the counter for the next launch.  Nothing waits on anything: no workgroup polls, so the order in which
+// items run (static striding or the dynamic claims of a data-parallel job) cannot deadlock and cannot change a bit of the result.
+// It is NOT the default: VERDICT r5 expected it to remove a "54 us float-atomic tail", but that figure is the intercept of a fit
+// over K, and the launch keeps 43-46 us of it with no output at all (ramp-up, imbalance); measured on one box (C2 block, 131 072
+// tokens, tools/wgrad_tail_probe.py): no partial traffic 804 us, float atomics 815, this form 837 (slot stores +9, the 48 last
+// arrivers reading 5 slots each at ~52 GB/s +24); whole C2 step 25.70 (atomics) -> 26.16 ms.  profiles/NEGATIVE_RESULTS.md, round 6.
+struct WgLa { float* ws; int* cnt; const int* slot0; };
+#ifndef WGLA_DIAG
+#define WGLA_DIAG 0      // TEMP (measurement): 1 no reduction loads, 2 no partial stores either, 3 plain (not sc1) partial stores
+#endif      // workspace slots of 256 x 256 floats; one counter and first slot per tile
 
 // NWM: wave rows (1: 128x256 tile, 4 waves, 2 workgroups per CU; 2: 256x256 tile, 8 waves, 1 per CU).  NST: LDS stages.
-template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST, bool DIAG, int EPI, bool GROUPED>
+template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST, bool DIAG, int EPI, bool GROUPED, bool WGLA = false>
 __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
                                         const bf16_t* __restrict__ B, int ldb, void* C, int ldc,
                                         const Epilogue& ep, int ksteps_per_split, int nsplit, int tiles_n,
                                         int ntiles, int64_t slab_stride,
-                                        unsigned long long* stamps, const WgProb* __restrict__ gprobs, const int4* __restrict__ gitems) {
+                                        unsigned long long* stamps, const WgProb* __restrict__ gprobs, const int4* __restrict__ gitems,
+                                        const WgLa la = WgLa{nullptr, nullptr, nullptr}) {
     // DIAG instantiation only (tools/gemm_timeline.py): workgroup 17, wave 0 records s_memtime at fixed points of its
     // first items into a buffer nothing else reads.  The product instantiation compiles the stamps away.
     constexpr int BM = 128 * NWM;
@@ -1536,10 +1557,12 @@ __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __res
     const int nk = cdiv(K, P_BK);
 
     int cur_split = 0;
+    int cur_meta = 0;                                     // grouped: the item's meta word (tile, K range index and count)
     auto item_coords = [&](int item, int& m0, int& n0, int& kt0, int& kt1) {
         if constexpr (GROUPED) {
             const int4 d = gitems[item];                  // wave-uniform index: scalar loads
-            const WgProb pr = gprobs[d.x];
+            const WgProb pr = gprobs[d.x & 15];
+            cur_meta = d.x;
             A = pr.A; B = pr.B; C = pr.C; M = pr.M; N = pr.N; lda = pr.lda; ldb = pr.ldb; ldc = pr.ldc;
             m0 = d.y & 0xFFFF;
             n0 = (int)((unsigned)d.y >> 16);
@@ -1728,6 +1751,7 @@ __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __res
         const int cm0 = m0, cn0 = n0;
         void* const Ccur = C;                  // (grouped: item_coords() below moves C / M / N / ldc on to the NEXT item's problem)
         const int Mcur = M, Ncur = N, ldccur = ldc;
+        const int meta = cur_meta;
         // split-K with a slab workspace: every split writes its own fp32 partial tile with the ordinary full-line
         // epilogue (plain stores run ~4-5x the f32-atomic rate and the sum is reproducible); gemm_slab_reduce folds them
         void* Cit = slab_stride ? (void*)((float*)C + (int64_t)cur_split * slab_stride) : C;
@@ -1785,6 +1809,62 @@ __device__ __forceinline__ void p4_body(int M, int N, int K, const bf16_t* __res
                     if (row < M && col < N) epi_finish8(ep, Cit, ldc, row, col, N, v0, v1, bias8, in[it]);
                 }
             }
+            }
+        } else if constexpr (GROUPED && WGLA) {
+            static_assert(NWM == 2, "the slot layout below is the 8-wave tile's");
+            const int nsp = (meta >> 12) & 0xFF, spi = (meta >> 4) & 0xFF, tile = (int)((unsigned)meta >> 20);
+            bool mine = true;                  // a tile with ONE K range: the partial is the sum
+            if (nsp > 1) {
+                typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+                const int s0 = la.slot0[tile];
+                const int voff = ((wave * 32) * 64 + lane) * 16;
+                {
+                    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(la.ws + (int64_t)(s0 + spi) * 65536), 0, 262144, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc[i][j]), rw, voff + (i * 4 + j) * 1024, 0, 16);   // aux 16 = sc1
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains, then the barrier, then ONE ticket
+                __builtin_amdgcn_s_barrier();
+                if (tid == 0) slot[4] = __hip_atomic_fetch_add(la.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                mine = __builtin_amdgcn_readfirstlane(slot[4]) == nsp - 1;
+                if (mine) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int q = 0; q < nsp; q++) {
+                        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(la.ws + (int64_t)(s0 + q) * 65536), 0, 262144, 0x00020000);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {             // sixteen 16-byte loads in flight per lane
+                            u32x4_ t[16];
+#pragma unroll
+                            for (int e = 0; e < 16; e++) t[e] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff + (h * 16 + e) * 1024, 0, 16);
+#pragma unroll
+                            for (int e = 0; e < 16; e++) acc[h * 4 + e / 4][e % 4] += __builtin_bit_cast(f32x4, t[e]);
+                        }
+                    }
+                    if (tid == 0) __hip_atomic_store(la.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+                }
+            }
+            if (mine) {
+                float* Cf = (float*)Ccur;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int col = cn0 + wn * 64 + j * 16 + (lane & 15);
+                        const int row0 = cm0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+                        if (col < Ncur) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+                                if (row0 + r < Mcur) Cf[(int64_t)(row0 + r) * ldccur + col] += acc[i][j][r];      // (no float atomic in this form)
+                        }
+                    }
             }
         } else {
             float* Cf = (float*)Ccur;
@@ -1851,6 +1931,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad_group_kernel(int K, const W
                                                                   int nitems, Epilogue ep) {
     p4_body<false, false, false, 2, 4, false, EPI_GENERIC, true>(0, 0, K, nullptr, 0, nullptr, 0, nullptr, 0, ep, 0, 1, 1, nitems, (int64_t)0,
                                                                  nullptr, gprobs, gitems);
+}
+// the same with the partial tiles through workspace slots and the last-arriving workgroup of a tile summing them (WgLa above)
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_group_la_kernel(int K, const WgProb* __restrict__ gprobs, const int4* __restrict__ gitems,
+                                                                     int nitems, Epilogue ep, WgLa la) {
+    p4_body<false, false, false, 2, 4, false, EPI_GENERIC, true, true>(0, 0, K, nullptr, 0, nullptr, 0, nullptr, 0, ep, 0, 1, 1, nitems, (int64_t)0,
+                                                                       nullptr, gprobs, gitems, la);
 }
 
 // dynamic-LDS opt-in, once per kernel
@@ -2105,6 +2191,11 @@ void sched_ws_free(SchedWs* w) {
 void wgrad_group_free(WgradGroup* g) {
     if (g && g->dev) { (void)hipFree(g->dev); g->dev = nullptr; g->dev_bytes = 0; g->key.clear(); }
 }
+void wgrad_ws_free(WgradWs* w) {
+    if (w && w->ptr) { (void)hipFree(w->ptr); w->ptr = nullptr; w->bytes = 0; }
+}
+// The last-arriver form runs where the caller hands over a partial-tile workspace (GemmExtra::wws): the model in deterministic
+// mode; the kernel-level entry point under COMPOSER_WGRAD_TAIL=la (read per call: tests, A/B runs).
 int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int nprob, int K, const GemmExtra& ex, bool* handled) {
     *handled = false;
     hipStream_t s = (hipStream_t)stream;
@@ -2129,6 +2220,8 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
     }
     put(&K, sizeof(K));
     put(&G, sizeof(G));
+    const bool la = ex.wws != nullptr;
+    put(&la, sizeof(la));
     if (key != g->key) {
         {   // building a table synchronises the stream: not inside a capture (cmp_train_step_launches on a model that has not stepped yet)
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -2149,6 +2242,8 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
         // (1 024 tokens, 12 tiles) ran 21 splits = 64 MB of atomics for 32 k-steps of work, 44 us per block; the minimum of
         //   ceil(nk / s) * 0.91 us + T * s * 256 KiB / 1.3 TB/s          (tools/kbench.py wgradgroup, same constants as below)
         // over s <= G / T is 4 splits there (~17 us) and stays at G / T for the benchmark shapes (K = 32 768 ... 131 072 tokens).
+        // (the last-arriver form takes the same cut: K ranges finer than one item per workgroup -- 7 ranges in 3 rounds at C4's 108
+        //  tiles -- measured 917 us without its reduction reads and 967 with them against 934 for the float-atomic form's 2 ranges)
         int sp = 1;
         {
             const int smax = std::max(1, std::min(G / T, nk));
@@ -2172,18 +2267,24 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
                 if (T * sp <= G && sp + 1 <= nk && tiles_of[i] <= spare) { split_of[i] = sp + 1; spare -= tiles_of[i]; }
         }
         // items in K-range-major order (range j of every problem that has one, tile by tile): consecutive items = one XCD's group
-        struct Item { int tile, kt0, kt1; };
+        struct Item { int tile, kt0, kt1, idx; };
         std::vector<Item> order;
+        std::vector<int> ranges_of(T, 0);              // K ranges a tile really has (a chunk that starts behind nk does not exist)
         int max_split = 0, longest = 0;
         for (int i = 0; i < nprob; i++) max_split = std::max(max_split, split_of[i]);
         for (int j = 0; j < max_split; j++)
             for (int t = 0; t < T; t++) {
                 const int spt = split_of[tiles[t].prob], chunk = cdiv(nk, spt);
                 if (j * chunk >= nk) continue;
-                order.push_back({t, j * chunk, std::min(nk, (j + 1) * chunk)});
+                order.push_back({t, j * chunk, std::min(nk, (j + 1) * chunk), ranges_of[t]});
+                ranges_of[t] += 1;
                 longest = std::max(longest, std::min(nk, (j + 1) * chunk) - j * chunk);
             }
         const int nitems = (int)order.size();
+        if (max_split > 255 || T > 4095) return CMP_OK;       // (the meta word's fields; far outside any model shape)
+        std::vector<int> slot0(T, 0);                   // first workspace slot of a tile; single-range tiles need none
+        int nslots = 0;
+        for (int t = 0; t < T; t++) { slot0[t] = nslots; if (ranges_of[t] > 1) nslots += ranges_of[t]; }
         {   // is one grouped launch cheaper than one split-K launch per problem?  (model above; K-independent overhead in k-steps)
             const double ov = 59.0;
             const double grouped = (double)longest * cdiv(nitems, G) + ov;
@@ -2199,7 +2300,9 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
                 return CMP_OK;
             }
         }
-        std::string host(WG_MAXP * sizeof(WgProb) + (size_t)nitems * sizeof(int4), '\0');
+        const size_t la_off = (WG_MAXP * sizeof(WgProb) + (size_t)nitems * sizeof(int4) + 127) / 128 * 128;      // counters on lines of their own
+        const int Tpad = (T + 3) / 4 * 4;
+        std::string host(la_off + (size_t)(Tpad + T) * sizeof(int), '\0');
         WgProb* hp = (WgProb*)&host[0];
         for (int i = 0; i < nprob; i++)
             hp[i] = WgProb{(const bf16_t*)probs[i].A, (const bf16_t*)probs[i].B, probs[i].C, probs[i].M, probs[i].N, probs[i].lda, probs[i].ldb,
@@ -2210,8 +2313,10 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
             const int x = item & 7;                                        // the XCD group of the item (ItemPuller): consecutive lin per group
             const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (item >> 3);
             const Item& it = order[lin];
-            hi[item] = make_int4(tiles[it.tile].prob, tiles[it.tile].m0 | (tiles[it.tile].n0 << 16), it.kt0, it.kt1);
+            const int meta = tiles[it.tile].prob | (it.idx << 4) | (ranges_of[it.tile] << 12) | (it.tile << 20);
+            hi[item] = make_int4(meta, tiles[it.tile].m0 | (tiles[it.tile].n0 << 16), it.kt0, it.kt1);
         }
+        memcpy(&host[la_off + (size_t)Tpad * sizeof(int)], slot0.data(), (size_t)T * sizeof(int));      // (the counters in front stay zero)
         HIP_CHECK(hipStreamSynchronize(s));            // the previous table of this group may still be in use / in flight (a rebuild is rare)
         if (g->dev_bytes < host.size()) {
             wgrad_group_free(g);
@@ -2221,9 +2326,19 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
         g->host.swap(host);
         HIP_CHECK(hipMemcpyAsync(g->dev, g->host.data(), g->host.size(), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        if (la && (size_t)nslots * 262144 > ex.wws->bytes) {       // (the stream is idle here: both synchronisations above)
+            wgrad_ws_free(ex.wws);
+            HIP_CHECK(hipMalloc((void**)&ex.wws->ptr, (size_t)nslots * 262144));
+            ex.wws->bytes = (size_t)nslots * 262144;
+        }
         g->key = key;
         g->nitems = nitems;
         g->grid = std::min(nitems, G);
+        g->nslots = nslots;
+        g->ntiles = T;
+        g->la_off = la_off;
+        g->la = la;
+        g->cnt_dirty = false;
         g->rebuilds += 1;
     }
     if (g->nitems == 0) return CMP_OK;                 // the cost model chose one launch per problem for these shapes
@@ -2235,12 +2350,23 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
     std::unique_lock<std::mutex> sched_lock;
     SchedWs* sched_used = nullptr;
     CHECK_SCHED(sched_next(s, ep, ex, sched_lock, &sched_used));
-    const size_t smem = (size_t)4 * (256 * P_BK * 2 + 256 * P_BK * 2) + 16;
+    const size_t smem = (size_t)4 * (256 * P_BK * 2 + 256 * P_BK * 2) + 32;      // + the scheduler words and the ticket word
     {
         static std::once_flag attr_once;
         std::call_once(attr_once, [smem]() {
             (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_la_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         });
+    }
+    const bool use_la = g->la && ex.wws && ex.wws->ptr && (size_t)g->nslots * 262144 <= ex.wws->bytes;
+    if (g->la && !use_la && g->nslots > 0) {
+        cmp_set_error("grouped weight gradients: the partial-tile workspace holds %zu bytes, the item table needs %zu", ex.wws ? ex.wws->bytes : (size_t)0,
+                      (size_t)g->nslots * 262144);
+        return CMP_ERR_STATE;
+    }
+    if (g->la && g->cnt_dirty) {        // a failed launch may have left tickets drawn
+        HIP_CHECK(hipMemsetAsync((char*)g->dev + g->la_off, 0, (size_t)((g->ntiles + 3) / 4 * 4) * sizeof(int), s));
+        g->cnt_dirty = false;
     }
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < nprob; i++) {
@@ -2248,12 +2374,21 @@ int wgrad_group_run(void* stream, WgradGroup* g, const WgradProblem* probs, int 
         bytes += 2.0 * ((double)probs[i].M * K + (double)K * probs[i].N) + 4.0 * probs[i].M * probs[i].N;
     }
     PROF_START(2, s);
-    gemm_wgrad_group_kernel<<<g->grid, 512, smem, s>>>(K, (const WgProb*)g->dev, (const int4*)((const char*)g->dev + WG_MAXP * sizeof(WgProb)),
-                                                        g->nitems, ep);
+    if (g->la) {
+        ep.atomic = 0;
+        int* cnt = (int*)((char*)g->dev + g->la_off);
+        const WgLa lav{g->nslots ? ex.wws->ptr : nullptr, cnt, cnt + (g->ntiles + 3) / 4 * 4};
+        gemm_wgrad_group_la_kernel<<<g->grid, 512, smem, s>>>(K, (const WgProb*)g->dev, (const int4*)((const char*)g->dev + WG_MAXP * sizeof(WgProb)),
+                                                               g->nitems, ep, lav);
+    } else {
+        gemm_wgrad_group_kernel<<<g->grid, 512, smem, s>>>(K, (const WgProb*)g->dev, (const int4*)((const char*)g->dev + WG_MAXP * sizeof(WgProb)),
+                                                            g->nitems, ep);
+    }
     PROF_STOP(2, s, flops, bytes);
     {
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
+            g->cnt_dirty = true;
             if (sched_used) sched_used->dirty = true;
             cmp_set_error("%s:%d: grouped wgrad launch failed: %s", __FILE__, __LINE__, hipGetErrorString(le));
             return CMP_ERR_HIP;
@@ -2267,10 +2402,12 @@ extern "C" int cmp_k_wgrad_group(void* stream, int nprob, const void* const* A, 
                                  float* const* C, const int* ldc, const int* M, const int* N, int K) {
     CMP_REQUIRE(nprob >= 1 && nprob <= WG_MAXP && A && B && C && lda && ldb && ldc && M && N, "wgrad_group: bad arguments");
     static thread_local WgradGroup grp;           // rebuilt whenever the problems change
+    static thread_local WgradWs wws;              // (kept for the life of the thread, like the item table)
     grp.force = true;                             // this entry point IS the grouped launch, whatever the cost model says
     WgradProblem pr[WG_MAXP];
     for (int i = 0; i < nprob; i++) pr[i] = WgradProblem{A[i], lda[i], B[i], ldb[i], C[i], ldc[i], M[i], N[i]};
     GemmExtra ex;
+    if (const char* e = getenv("COMPOSER_WGRAD_TAIL")) if (e[0] == 'l') ex.wws = &wws;
     bool handled = false;
     CHECK_SCHED(wgrad_group_run(stream, &grp, pr, nprob, K, ex, &handled));
     CMP_REQUIRE(handled, "wgrad_group: these shapes do not fit the grouped kernel (K %% 32, leading dimensions %% 8, 16-byte alignment, < 2 GiB operands)");

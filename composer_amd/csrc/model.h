@@ -149,6 +149,7 @@ struct cmp_model {
     int64_t embed_ws_words = 0;
     void* dmask2 = nullptr;            // the attention branch's masked gradient: both masked copies of a block stay live until its grouped wgrad launch
     std::vector<WgradGroup> wgrad_groups;      // per decoder block: item table + problem descriptors of that launch
+    WgradWs wgrad_ws;                          // ... and the partial-tile workspace they share (one launch at a time on the stream)
     void* ln_ws = nullptr;
     void* slab = nullptr;              // split-K slab workspace (deterministic mode only)
     int64_t slab_bytes = 0;

@@ -405,6 +405,7 @@ extern "C" int cmp_model_destroy(cmp_model* m) {
     if (m->dec) decode_state_free(m->dec);
     for (void* p : m->allocs) if (p) hipFree(p);
     for (auto& wg : m->wgrad_groups) wgrad_group_free(&wg);
+    wgrad_ws_free(&m->wgrad_ws);
     if (m->metrics_host) hipHostFree(m->metrics_host);
     if (m->stage_metrics) hipHostFree(m->stage_metrics);
     for (int i = 0; i < cmp_model::STAGES; i++) {
@@ -979,7 +980,9 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     // (non-deterministic) split-K form they go out as ONE grouped launch behind the block's attention backward (gemm.hip:
     // gemm_wgrad_group_kernel) -- a quarter of the f32-atomic traffic of four split-K launches, equal k-steps per workgroup.
     // Until then both masked gradient copies of the block stay live: the MLP branch's in dmask, the attention branch's in dmask2.
-    const bool grouped = ln && dt == CMP_BF16 && !m->slab;
+    // (COMPOSER_DETERMINISTIC=1 takes the grouped launch too since round 6, in its last-arriver form: partial tiles summed in the
+    //  order of the K ranges, no float atomics -- the deterministic step runs the launch order of the default one)
+    const bool grouped = ln && dt == CMP_BF16;
     CMP_REQUIRE(!fused || grouped, "backward: the fused block path needs the grouped weight-gradient order");
     if (grouped && (int)m->wgrad_groups.size() != m->L) m->wgrad_groups.resize(m->L);
     for (int i = m->L - 1; i >= 0; i--) {
@@ -1042,6 +1045,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
             ex.max_wgs = m->ctx->dp_on() ? m->ctx->gemm_max_wgs : 0;
             ex.dp = m->ctx->dp_on();
             ex.sched = &m->ctx->gemm_sched;
+            if (m->slab) ex.wws = &m->wgrad_ws;        // deterministic mode: partial tiles through workspace slots, summed by each tile's last arriver (gemm.hip: WgLa)
             bool handled = false;
             CHECK_RC(wgrad_group_run(s, &m->wgrad_groups[i], wp, 4, M, ex, &handled));
             if (!handled) {          // shapes outside the grouped kernel's domain (M % 32, ...): one launch each, as without grouping

@@ -105,7 +105,7 @@ def wgrad_group(lib, As, Bs, Cs, K):
                                     [(64, 64)], [(264, 520), (8, 8), (1000, 136)],                 # ragged tiles, one problem, tiny problems
                                     [(256, 256)] * 8])
 def test_grouped_weight_gradients(lib, K, shapes):
-    """cmp_k_wgrad_group: C_i += A_i^T . B_i for all problems in ONE launch (stream-K items over all output tiles, f32 atomics)
+    """cmp_k_wgrad_group: C_i += A_i^T . B_i for all problems in ONE launch (all output tiles cut into the same K ranges, f32 atomics)
     against float64 products; C_i starts non-zero (accumulate semantics) and the bytes next to every C_i stay untouched."""
     g = torch.Generator().manual_seed(K + len(shapes))
     As = [torch.randn(K, m, generator=g).to(torch.bfloat16).cuda() for m, n in shapes]
@@ -150,6 +150,31 @@ def test_grouped_weight_gradients_at_the_timed_depth(lib):
     wgrad_group(lib, [a.cuda() for a in As], [b.cuda() for b in Bs], Cs, K)
     for a, b, c in zip(As, Bs, Cs):
         ref = torch.from_numpy(a.double().numpy().T @ b.double().numpy())
+        assert rel_err(c, ref) < 5e-5, (a.shape, b.shape)
+
+
+@pytest.mark.parametrize("K,shapes", [(65536, [(768, 3072), (3072, 768), (768, 768), (768, 2304)]),      # a C4 block at its timed depth
+                                      (4096, [(512, 2048), (2048, 512), (512, 512), (512, 1536)]), (96, [(264, 520), (8, 8)])])
+def test_grouped_weight_gradients_last_arriver_form_is_bitwise_reproducible(lib, K, shapes, monkeypatch):
+    """Round 6: the grouped launch without float atomics (COMPOSER_WGRAD_TAIL=la here; what COMPOSER_DETERMINISTIC=1 trains with) -- partial
+    tiles through workspace slots, summed by the LAST-ARRIVING workgroup of a tile in the order of the K ranges (gemm.hip: WgLa).  Two
+    launches from the same start give the same bits, also with the items claimed dynamically (a data-parallel job), the per-tile
+    tickets are back at zero for the next launch, and the values are the float64 products."""
+    monkeypatch.setenv("COMPOSER_WGRAD_TAIL", "la")
+    g = torch.Generator().manual_seed(K)
+    As = [torch.randn(K, m, generator=g).to(torch.bfloat16).cuda() for m, n in shapes]
+    Bs = [torch.randn(K, n, generator=g).to(torch.bfloat16).cuda() for m, n in shapes]
+    C0 = [torch.randn(m, n, generator=g) for m, n in shapes]
+    outs = []
+    for items in ("static", "dynamic", "static"):
+        monkeypatch.setenv("COMPOSER_GEMM_ITEMS", items)
+        Cs = [c.clone().cuda() for c in C0]
+        wgrad_group(lib, As, Bs, Cs, K)
+        outs.append([c.cpu() for c in Cs])
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, b, c0, c in zip(As, Bs, C0, outs[0]):
+        ref = c0.double() + torch.from_numpy(a.float().cpu().double().numpy().T @ b.float().cpu().double().numpy())
         assert rel_err(c, ref) < 5e-5, (a.shape, b.shape)
 
 
