@@ -96,6 +96,11 @@ SIGNATURES = {
     "cmp_k_embed_fwd_stats": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _f, _u64, _u32]),
     "cmp_k_ln_fold_prep": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i]),
     "cmp_gemm_ln_next": (_i, [_P, _i, _f, _P, _P, _P, _P]),
+    "cmp_gemm_ln_scale_next": (_i, [_P, _i, _f]),
+    "cmp_attn_bwd_ln_next": (_i, [_P]),
+    "cmp_k_ln_stats_merge": (_i, [_P, _P, _i, _f, _P, _P, _i]),
+    "cmp_k_layernorm_bwd_prescaled": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P, _P, _f, _u64, _u32]),
+    "cmp_k_wgrad_ln_fix": (_i, [_P, _P, _i, _i, _P, _P, _P]),
     "cmp_k_layernorm_bwd_parts": (_i, [_P, _P, _P, _P, _P, _P, _f, _P, _P, _P, _P, _P, _P, _i, _i, _P, _P, _f, _u64, _u32]),
     "cmp_model_path_info": (_i, [_P, C.POINTER(_i), C.POINTER(_i64)]),
     "cmp_k_wgrad_group": (_i, [_P, _i, _P, _P, _P, _P, _P, _P, _P, _P, _i]),
@@ -112,7 +117,7 @@ SIGNATURES = {
 
 # entry points added after round 3: an OLDER build of the library loaded through COMPOSER_HIP_LIB as the other arm of an A/B
 # timing (tools/ab_step.py) may lack them; the package's own library must export every symbol
-_ADDED_LATER = {"cmp_dp_rccl_version", "cmp_dp_allreduce_pattern", "cmp_dp_init_exchange", "cmp_train_step_graph_probe", "cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
+_ADDED_LATER = {"cmp_gemm_ln_scale_next", "cmp_attn_bwd_ln_next", "cmp_k_layernorm_bwd_prescaled", "cmp_k_wgrad_ln_fix", "cmp_k_ln_stats_merge", "cmp_dp_rccl_version", "cmp_dp_allreduce_pattern", "cmp_dp_init_exchange", "cmp_train_step_graph_probe", "cmp_train_step_launches", "cmp_k_embed_fwd_stats", "cmp_k_ln_fold_prep", "cmp_gemm_ln_next", "cmp_k_layernorm_bwd_parts", "cmp_model_path_info", "cmp_forward_ex", "cmp_hidden_get_at", "cmp_dp_stats", "cmp_prof_end2", "cmp_prof_pause", "cmp_prof_resume", "cmp_k_wgrad_group", "cmp_k_embed_bwd_v"}
 
 _lib = None
 
@@ -159,7 +164,7 @@ def mapped_runtime_libraries():
 
 
 def check_single_runtime():
-    """Raises when two DIFFERENT copies of the HIP runtime, of RCCL or of the HSA runtime are mapped into this process.
+    """Raises when two DIFFERENT copies of the HIP runtime or of RCCL are mapped into this process.
 
     libcomposer_hip.so asks the dynamic linker for `libamdhip64.so.7` / `librccl.so.1` (rpath /opt/rocm/lib); torch's wheel
     bundles its own copies and asks for them as `libamdhip64.so` / `librccl.so`.  With torch imported FIRST the linker hands the
@@ -168,7 +173,10 @@ def check_single_runtime():
     initialises both sees "No HIP GPUs are available" from torch.cuda at best, and its ranks may sit on another RCCL than the
     peers of the job.  The rule ("Library load order"): a process that uses torch at all imports it before
     composer_amd loads the library -- `composer_amd.cli` does so itself when WORLD_SIZE > 1."""
-    dup = {k: v for k, v in mapped_runtime_libraries().items() if len(v) > 1}
+    # (libhsa-runtime64 is reported by runtime_info() but not judged here: rocprofv3's preloaded tool maps /opt/rocm's copy before
+    #  python starts and torch then brings its own -- profiled runs have always worked that way; what the library itself binds, and
+    #  what breaks when doubled, are the HIP runtime and RCCL)
+    dup = {k: v for k, v in mapped_runtime_libraries().items() if len(v) > 1 and k != "libhsa-runtime64"}
     if dup:
         raise HipLibraryError(
             "two copies of the GPU runtime are mapped into this process: %s.  libcomposer_hip.so was loaded before torch was "

@@ -717,7 +717,7 @@ template <typename T, int D, bool DROP, int KS>
 __device__ __forceinline__ void attn_dq_body(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
                                              const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dqkv,
                                              float* __restrict__ bias_grad, int Tn, int H, float scale, DropCfg drop, int plan_u,
-                                             int ks_blk) {
+                                             int ks_blk, const AttnLnRows lr = AttnLnRows()) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -871,8 +871,10 @@ __device__ __forceinline__ void attn_dq_body(const T* __restrict__ qkv, const T*
 #pragma unroll
                     for (int r = 0; r < 16; r++) dq[dt][r] += mg[((w * G::DT + dt) * 16 + r) * 64 + lane];
         }
+        // (lr: the stored rows carry the rstd of their token's LayerNorm as a factor; see AttnLnRows)
+        const float row_rs = (lr.rstd && qvalid) ? lr.rstd[(int64_t)b * Tn + q] : 1.f;
 #pragma unroll
-        for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale * keep_scale, h);
+        for (int dt = 0; dt < G::DT; dt++) store_t_tile<T, D>(dqg, rs, q, qvalid, dt, dq[dt], scale * keep_scale * row_rs, h);
         if (bias_grad) colsum_t_tiles<T, D>(bias_grad + hd * D, qvalid, dq, scale * keep_scale, h, lane);
     }
 }
@@ -882,6 +884,14 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T*
                     float* __restrict__ delta, T* __restrict__ dqkv, float* __restrict__ bias_grad, int Tn, int H, float scale,
                     DropCfg drop, int plan_u) {
     attn_dq_body<T, D, DROP, 0>(qkv, o, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, plan_u, 0);
+}
+// (the same with the stored rows scaled by their token's LayerNorm rstd: AttnLnRows, round 6)
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW_Q))
+void attn_dq_ln_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o, const float* __restrict__ lse,
+                    float* __restrict__ delta, T* __restrict__ dqkv, float* __restrict__ bias_grad, int Tn, int H, float scale,
+                    DropCfg drop, int plan_u, AttnLnRows lr) {
+    attn_dq_body<T, D, DROP, 0>(qkv, o, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, plan_u, 0, lr);
 }
 
 // =================================================================================================
@@ -895,7 +905,8 @@ void attn_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T*
 template <typename T, int D, bool DROP, int KS>
 __device__ __forceinline__ void attn_dkv_body(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
                                               const float* __restrict__ delta, T* __restrict__ dqkv, float* __restrict__ bias_grad,
-                                              int Tn, int H, float scale, DropCfg drop, const T* __restrict__ o, int ks_blk) {
+                                              int Tn, int H, float scale, DropCfg drop, const T* __restrict__ o, int ks_blk,
+                                              const AttnLnRows lr = AttnLnRows()) {
     using G = Geo<T, D>;
     constexpr bool EXACT = AT<T>::EXACT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1111,10 +1122,11 @@ __device__ __forceinline__ void attn_dkv_body(const T* __restrict__ qkv, const T
                         dv[dt][r] += mg[((w * 2 * G::DT + 2 * dt + 1) * 16 + r) * 64 + lane];
                     }
         }
+        const float row_rs = (lr.rstd && kvalid) ? lr.rstd[(int64_t)b * Tn + key] : 1.f;
 #pragma unroll
         for (int dt = 0; dt < G::DT; dt++) {
-            store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale * keep_scale, h);
-            store_t_tile<T, D>(dvg, rs, key, kvalid, dt, dv[dt], keep_scale, h);
+            store_t_tile<T, D>(dkg, rs, key, kvalid, dt, dk[dt], scale * keep_scale * row_rs, h);
+            store_t_tile<T, D>(dvg, rs, key, kvalid, dt, dv[dt], keep_scale * row_rs, h);
         }
         if (bias_grad) {
             colsum_t_tiles<T, D>(bias_grad + E + hd * D, kvalid, dk, scale * keep_scale, h, lane);
@@ -1129,6 +1141,14 @@ __global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_kernel(const 
                                                                           float* __restrict__ bias_grad, int Tn, int H, float scale,
                                                                           DropCfg drop) {
     attn_dkv_body<T, D, DROP, 0>(qkv, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, nullptr, 0);
+}
+template <typename T, int D, bool DROP>
+__global__ __launch_bounds__(256, (Occ<T, D>::MINW)) void attn_dkv_ln_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                                          const float* __restrict__ lse,
+                                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                                          float* __restrict__ bias_grad, int Tn, int H, float scale,
+                                                                          DropCfg drop, AttnLnRows lr) {
+    attn_dkv_body<T, D, DROP, 0>(qkv, d_o, lse, delta, dqkv, bias_grad, Tn, H, scale, drop, nullptr, 0, lr);
 }
 // The whole backward of a small grid in one launch: grid (2 * ceil(T/32), B*H); even x = dK/dV of key block x/2, odd x = dQ of query
 // block ceil(T/32) - 1 - x/2 -- the heaviest blocks of both roles first, the lightest last, so the second round of workgroups (two
@@ -1265,7 +1285,37 @@ static int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int B
 }
 template <typename T, int D>
 static int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                      void* dqkv, int B, int Tn, int H, float scale, DropCfg d, float* bias_grad) {
+                      void* dqkv, int B, int Tn, int H, float scale, DropCfg d, float* bias_grad, AttnLnRows lr) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (lr.rstd) {
+            // the backward pass of the fused block path (bf16, chip-filling launches): the 128-row kernels with rstd-scaled stores (AttnLnRows)
+            size_t smem = 4 * 64 * Geo<T, D>::S * sizeof(T);
+            if (smem + 1536 > 65536) {
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_dq_ln_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_dq_ln_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_dkv_ln_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem + 1536));
+                HIP_CHECK(hipFuncSetAttribute((const void*)attn_dkv_ln_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem + 1536));
+            }
+            const double fl = (double)B * H * (double)Tn * Tn * D;
+            static const int wgs_per_cu_ln = attn_wgs_per_cu(attn_dq_ln_kernel<T, D, true>, smem);
+            const int plan_u = attn_plan_u(Tn, B * H, wgs_per_cu_ln);
+            const dim3 qgrid = attn_plan_grid(Tn, B * H, plan_u);
+            const dim3 kgrid(attn_grid_x(Tn, B * H), B * H);
+            PROF_START(4, s);
+            if (d.thr) attn_dq_ln_kernel<T, D, true><<<qgrid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d, plan_u, lr);
+            else attn_dq_ln_kernel<T, D, false><<<qgrid, 256, smem, s>>>((const T*)qkv, (const T*)o, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d, plan_u, lr);
+            PROF_STOP(4, s, 3.0 * fl, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));
+            KERNEL_CHECK();
+            PROF_START(5, s);
+            if (d.thr) attn_dkv_ln_kernel<T, D, true><<<kgrid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d, lr);
+            else attn_dkv_ln_kernel<T, D, false><<<kgrid, 256, smem + 384 * sizeof(float), s>>>((const T*)qkv, (const T*)d_o, lse, delta, (T*)dqkv, bias_grad, Tn, H, scale, d, lr);
+            PROF_STOP(5, s, 4.0 * fl, (double)B * Tn * H * (6.0 * D * sizeof(T) + 8.0));
+            KERNEL_CHECK();
+            return CMP_OK;
+        }
+    } else {
+        CMP_REQUIRE(!lr.rstd, "attention backward: LayerNorm row scaling exists in bf16 only");
+    }
     if constexpr (std::is_same<T, bf16_t>::value && D <= 32) {
         // one launch, both roles: LDS = the larger of the two (dQ double-buffers its 256-key tiles)
         const size_t smem_ks = attn_ks_smem<T, D>(), smem_kv = smem_ks / 2 + 3 * 256 * sizeof(float);
@@ -1412,21 +1462,30 @@ extern "C" int cmp_attn_bwd_bias_next(float* out) {
     return CMP_OK;
 }
 
+// ... and (round 6) stores its gradient rows scaled by rstd[token] (AttnLnRows, common.h)
+static thread_local AttnLnRows t_attn_ln_next;
+extern "C" int cmp_attn_bwd_ln_next(const float* rstd) {
+    t_attn_ln_next = AttnLnRows{rstd};
+    return CMP_OK;
+}
+
 extern "C" int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
                               float* delta_ws, void* dqkv, int B, int T, int H, int D, int scale, int dtype,
                               float p_drop, uint64_t seed, uint32_t rng_stream) {
     float* bias_grad = t_attn_bias_next;
     t_attn_bias_next = nullptr;
+    const AttnLnRows lr = t_attn_ln_next;
+    t_attn_ln_next = AttnLnRows();
     return attn_bwd_run(stream, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, D, scale ? 1.0f / sqrtf((float)D) : 1.0f, dtype, p_drop, seed,
-                        rng_stream, bias_grad);
+                        rng_stream, bias_grad, lr);
 }
 
 int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
                  int B, int T, int H, int D, float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
-                 float* bias_grad) {
+                 float* bias_grad, AttnLnRows lr) {
     if (B * T == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     DropCfg d = make_drop(p_drop, seed, rng_stream);
-    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }
-    else { DISPATCH_D(float, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad) }
+    if (dtype == CMP_BF16) { DISPATCH_D(bf16_t, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad, lr) }
+    else { DISPATCH_D(float, launch_bwd, s, qkv, o, d_o, lse, delta_ws, dqkv, B, T, H, sc, d, bias_grad, lr) }
 }

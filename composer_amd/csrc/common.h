@@ -81,6 +81,10 @@ struct LnEpi {
     const float* gamma = nullptr;     // residual rebuild: [N] gamma, beta of the LayerNorm whose output is the residual operand
     const float* beta = nullptr;
     float* out_part = nullptr;        // [rows][N / 256][2] partial statistics of the OUTPUT rows (null: not wanted)
+    // Round 6, the backward pass of the fused block path ("scale" mode, with in_part): nothing is normalised, the row's rstd is a
+    // FACTOR -- EPI_GELUGRAD writes rstd o (acc * gelu'(aux)) (the column sums of the unscaled product still go to the launch's colsum);
+    // EPI_RESID adds rstd o resid instead of resid (model.hip: backward).
+    int scale = 0;
 };
 // (mean, rstd) of a row from its np partials of 256 columns each
 __device__ __forceinline__ void ln_merge_parts(const float* __restrict__ p, int np, float eps, float& mean, float& rstd) {
@@ -139,9 +143,15 @@ void wgrad_group_free(WgradGroup* g);
 int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const void* A, int lda, const void* Bm, int ldb,
              void* C, int ldc, const float* bias, int act, void* aux, int ldaux, const void* resid, int ldr, int out_fp32,
              int splitk, float p_drop, uint64_t seed, uint32_t rng_stream, int flags, const GemmExtra& ex);
+// Round 6 (backward pass of the fused block path): the attention backward kernels store rstd o [dQ | dK | dV], rstd being that of the
+// token's row in the LayerNorm whose output fed c_attn (ln_stats_merge_kernel) -- the c_attn weight gradient then
+// runs on the raw rows (elementwise.hip: wgrad_ln_fix_kernel).  The bias gradient stays the column sums of the unscaled gradient.
+struct AttnLnRows {
+    const float* rstd = nullptr;      // [tokens]; null: nothing of this
+};
 int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
                  int B, int T, int H, int D, float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
-                 float* bias_grad);
+                 float* bias_grad, AttnLnRows lr = AttnLnRows());
 int attn_fwd_run(void* stream, const void* qkv, void* o, float* lse, int B, int T, int H, int D, float sc, int dtype, float p_drop,
                  uint64_t seed, uint32_t rng_stream, const float* amask = nullptr);
 int attn_probs_run(void* stream, const void* qkv, const float* lse, const float* amask, float* out, int B, int q0, int T, int H, int D,

@@ -428,7 +428,8 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, const float* __res
 // FUSED (the LayerNorm-fused block path, bf16): the forward pass never ran this LayerNorm as a kernel -- its statistics arrive as
 // the partials the producing GEMM epilogue left (`part`, np segments of 256 columns, merged here), and its OUTPUT, which only
 // the weight-gradient GEMM of the consuming Conv1D needs, is written here (`yout` = xhat * gamma + beta) beside dx.
-template <typename T, int MAXI, bool FUSED = false>
+// PRE (with mean / rstd arrays, round 6): dy holds rstd o gradient, like LnBwdFused::prescaled of the FUSED form
+template <typename T, int MAXI, bool FUSED = false, bool PRE = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const T* __restrict__ resid,
@@ -507,6 +508,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
             rs = __builtin_amdgcn_rsqf(m2 / (256.0f * (float)fz.np) + fz.eps);
         }
+        // prescaled: dy holds rstd o gradient (the A operand of the dgrad GEMM in front was stored rstd-scaled, model.hip: backward);
+        // the row's 1 / rstd gives the gradient back -- everything below is the formula of the plain form
+        float dsc = 1.0f;
+        if constexpr (FUSED) { if (fz.prescaled) dsc = 1.0f / rs; }
+        if constexpr (PRE) dsc = 1.0f / rs;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXI; i++) {
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             if (c < chunks) {
 #pragma unroll
                 for (int j = 0; j < VN; j++) {
-                    float d = cur.dy[i].get(j);
+                    float d = cur.dy[i].get(j) * dsc;
                     float xh = (cur.x[i].get(j) - mu) * rs;
                     float g = d * gm[i][j];
                     s1 += g;
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int j = 0; j < VN; j++) {
                     float xh = (cur.x[i].get(j) - mu) * rs;
-                    float g = cur.dy[i].get(j) * gm[i][j];
+                    float g = cur.dy[i].get(j) * dsc * gm[i][j];
                     float v = rs * (g - s1 - xh * s2);
                     if (resid) v += cur.r[i].get(j);
                     o.set(j, v);
@@ -1241,6 +1247,46 @@ extern "C" int cmp_k_layernorm_bwd_fused(void* stream, const void* dy, const voi
 // The form the LayerNorm-fused block path uses (bf16, E a multiple of 256): the row statistics come as partials [rows][E/256][2]
 // (mean, M2 per 256-column segment, as the producing GEMM epilogue / embedding kernel leaves them) and the LayerNorm OUTPUT
 // yout = xhat * gamma + beta is written beside dx (null: not wanted).  dmask (null: not wanted) is written whatever p_drop is.
+// Round 6's backward pass: (mean, rstd) of every row from its partial statistics, for any number of LayerNorm sites in ONE launch
+// (grid.y = site): the backward pass of the fused block path merges all 2L sites of a step up front, and every consumer (the
+// LayerNorm backward kernels, the attention backward kernels) reads plain per-row arrays.
+struct LnMergeSite { const float* part; float* mean; float* rstd; };
+__global__ void ln_stats_merge_kernel(const LnMergeSite* __restrict__ sites, int np, float eps, int rows) {
+    const LnMergeSite st = sites[blockIdx.y];
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    float mu, rs;
+    ln_merge_parts(st.part + (int64_t)row * np * 2, np, eps, mu, rs);
+    st.mean[row] = mu;
+    st.rstd[row] = rs;
+}
+int ln_stats_merge_run(void* stream, const void* sites_dev, int nsites, int np, float eps, int rows) {
+    if (rows == 0 || nsites == 0) return CMP_OK;
+    ln_stats_merge_kernel<<<dim3(cdiv(rows, 256), nsites), 256, 0, (hipStream_t)stream>>>((const LnMergeSite*)sites_dev, np, eps, rows);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
+// kernel-level forms (tests): one site; and the LayerNorm backward on dy = rstd o gradient with the merged statistics
+extern "C" int cmp_k_ln_stats_merge(void* stream, const float* part, int np, float eps, float* mean, float* rstd, int rows) {
+    CMP_REQUIRE(part && mean && rstd && np >= 1 && np <= 8, "ln_stats_merge: bad arguments");
+    LnMergeSite h{part, mean, rstd};
+    LnMergeSite* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, sizeof(h)));
+    hipError_t e = hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream);
+    int rc = e == hipSuccess ? ln_stats_merge_run(stream, d, 1, np, eps, rows) : CMP_ERR_HIP;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d);
+    return rc;
+}
+extern "C" int cmp_k_layernorm_bwd_prescaled(void* stream, const void* dy_scaled, const void* x, const float* gamma, const float* mean,
+                                             const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta, void* ws,
+                                             int rows, int E, void* dmask, float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream) {
+    return layernorm_bwd_run(stream, dy_scaled, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, ws, rows, E, CMP_BF16, dmask, colsum,
+                             p_drop, seed, rng_stream, false, nullptr, true, true);
+}
+extern "C" int cmp_k_wgrad_ln_fix(void* stream, float* G, int rows, int cols, const float* gamma, const float* beta, const float* colsum) {
+    return wgrad_ln_fix_run(stream, G, rows, cols, gamma, beta, colsum, nullptr, 0, 0, nullptr, nullptr, nullptr);
+}
 extern "C" int cmp_k_layernorm_bwd_parts(void* stream, const void* dy, const void* x, const float* gamma, const float* beta,
                                          const float* part, float eps, const void* resid, void* dx, void* yout, float* dgamma,
                                          float* dbeta, void* ws, int rows, int E, void* dmask, float* colsum, float p_drop,
@@ -1251,11 +1297,58 @@ extern "C" int cmp_k_layernorm_bwd_parts(void* stream, const void* dy, const voi
                              seed, rng_stream, false, &fz, true);
 }
 
+// Round 6 (the fused block path's backward pass): a Conv1D weight gradient n^T . D with n = LayerNorm(r) is accumulated by the
+// grouped launch as R = r^T . D' on the RAW rows r and D' = rstd o D (what the producing epilogue stored), so that n is never written:
+//   n^T . D = gamma o (R - 1 (x) (mean^T . D')) + beta (x) colsum(D),   and   mean^T . D' = (1/E) 1^T . r^T . D' = the COLUMN MEANS of R
+// (a row's mean is the mean of that row of r as stored -- what the partial statistics were taken from), so the pass needs nothing
+// but R itself, gamma, beta and colsum(D) (= the Conv1D's bias gradient, summed by whoever produced D'): per column, the mean over
+// the E rows, then G[k, j] = gamma[k] * (R[k, j] - mean_j) + beta[k] * colsum[j].  One launch for the matrices of a block; a
+// workgroup owns 32 columns of one matrix (32 row groups x 32 columns).
+struct LnFixDesc { float* G; const float* gamma; const float* beta; const float* colsum; int rows, cols, blk0, pad; };
+__global__ __launch_bounds__(1024) void wgrad_ln_fix_kernel(LnFixDesc d0, LnFixDesc d1) {
+    __shared__ float part[32][33];
+    const LnFixDesc d = ((int)blockIdx.x >= d1.blk0 && d1.G) ? d1 : d0;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 columns (128-byte runs) x 32 row groups
+    const int c = ((int)blockIdx.x - d.blk0) * 32 + tx;
+    const bool ok = c < d.cols;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                       // independent chains: the loads of a thread overlap
+    if (ok) {
+        int k = ty;
+        for (; k + 96 < d.rows; k += 128) {
+            s0 += d.G[(int64_t)k * d.cols + c];
+            s1 += d.G[(int64_t)(k + 32) * d.cols + c];
+            s2 += d.G[(int64_t)(k + 64) * d.cols + c];
+            s3 += d.G[(int64_t)(k + 96) * d.cols + c];
+        }
+        for (; k < d.rows; k += 32) s0 += d.G[(int64_t)k * d.cols + c];
+    }
+    part[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 32; t++) tot += part[t][tx];                    // (every row group adds them in the same order)
+    if (!ok) return;
+    const float mean = tot / (float)d.rows, bc = d.colsum[c];
+    for (int k = ty; k < d.rows; k += 32) {
+        const int64_t at = (int64_t)k * d.cols + c;
+        d.G[at] = fmaf(d.gamma[k], d.G[at] - mean, d.beta[k] * bc);
+    }
+}
+int wgrad_ln_fix_run(void* stream, float* G0, int rows0, int cols0, const float* gamma0, const float* beta0, const float* colsum0,
+                     float* G1, int rows1, int cols1, const float* gamma1, const float* beta1, const float* colsum1) {
+    CMP_REQUIRE(G0 && gamma0 && beta0 && colsum0 && rows0 > 0 && cols0 > 0, "wgrad_ln_fix: bad arguments");
+    LnFixDesc d0{G0, gamma0, beta0, colsum0, rows0, cols0, 0, 0};
+    LnFixDesc d1{G1, gamma1, beta1, colsum1, rows1, cols1, cdiv(cols0, 32), 0};
+    const int grid = cdiv(cols0, 32) + (G1 ? cdiv(cols1, 32) : 0);
+    wgrad_ln_fix_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(d0, d1);
+    KERNEL_CHECK();
+    return CMP_OK;
+}
 // deterministic: the per-workgroup partials are folded by ONE thread per column in workgroup order (no float atomics)
 int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* resid, void* dx, float* dgamma, float* dbeta, void* ws, int rows, int E, int dtype, void* dmask,
                       float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic, const LnBwdFused* fz,
-                      bool keep_dmask) {
+                      bool keep_dmask, bool prescaled) {
     int rc = ln_check(E, dtype);
     if (rc) return rc;
     if (rows == 0) return CMP_OK;
@@ -1284,11 +1377,20 @@ int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* 
         if (smem > 65536) HIP_CHECK(hipFuncSetAttribute((const void*)layernorm_bwd_kernel<bf16_t, MI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         layernorm_bwd_kernel<bf16_t, MI, true><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)resid, (bf16_t*)dx, (float*)ws, rows, E, (bf16_t*)dmask, want_cs, dcfg, dg_, dbeta, colsum, *fz); \
     } while (0)
+#define LN_BWDP(MI) do { \
+        if (smem > 65536) HIP_CHECK(hipFuncSetAttribute((const void*)layernorm_bwd_kernel<bf16_t, MI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        layernorm_bwd_kernel<bf16_t, MI, false, true><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)resid, (bf16_t*)dx, (float*)ws, rows, E, (bf16_t*)dmask, want_cs, dcfg, dg_, dbeta, colsum); \
+    } while (0)
+    if (prescaled && !fz) {
+        CMP_REQUIRE(dtype == CMP_BF16 && maxi <= 4, "layernorm_bwd: the prescaled form exists for bf16 rows of at most 2048 columns");
+        if (maxi == 1) LN_BWDP(1); else if (maxi == 2) LN_BWDP(2); else LN_BWDP(4);
+    } else
     if (fz) { if (maxi == 1) LN_BWDF(1); else if (maxi == 2) LN_BWDF(2); else if (maxi <= 4) LN_BWDF(4); else LN_BWDF(8); }
     else if (dtype == CMP_BF16) { if (maxi == 1) LN_BWD(bf16_t, 1); else if (maxi == 2) LN_BWD(bf16_t, 2); else if (maxi <= 4) LN_BWD(bf16_t, 4); else LN_BWD(bf16_t, 8); }
     else { if (maxi == 1) LN_BWD(float, 1); else if (maxi == 2) LN_BWD(float, 2); else if (maxi <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
 #undef LN_BWD
 #undef LN_BWDF
+#undef LN_BWDP
     KERNEL_CHECK();
     if (!direct)
         ln_param_reduce_kernel<<<dim3(cdiv(3 * E, 256), deterministic ? 1 : std::min(grid, 32)), 256, 0, s>>>((const float*)ws, dgamma, dbeta, colsum, grid, E);

@@ -598,8 +598,9 @@ template <int KIND, int LNM, int NP, int NPRE>
 __device__ __forceinline__ void epi_prefetch(const Epilogue& ep, int row0, int col, int lane, EpiPre<KIND, LNM, NP>& pre,
                                              const char* fold_img = nullptr) {
     constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
-    constexpr bool LN_IN = (LNM & 1) != 0;
-    if constexpr (LN_IN && KIND != EPI_RESID) {
+    constexpr bool LN_IN = (LNM & 1) != 0, SCALE = (LNM & 4) != 0;
+    constexpr bool FOLDK = LN_IN && KIND != EPI_RESID && KIND != EPI_GELUGRAD;      // LayerNorm folded into c_attn / c_fc / the logits
+    if constexpr (FOLDK) {
         // from the wave's DMA image (fold_dma); the caller has waited for it
 #pragma unroll
         for (int h = 0; h < 2; h++)
@@ -629,7 +630,7 @@ __device__ __forceinline__ void epi_prefetch(const Epilogue& ep, int row0, int c
 #pragma unroll
         for (int j = 0; j < 4; j++) { pre.b[j] = b0[j]; pre.b[4 + j] = b1[j]; }
     }
-    if constexpr (LN_IN) {
+    if constexpr (LN_IN && !SCALE) {
         const float* pa = KIND == EPI_RESID ? ep.ln.gamma : ep.ln.cs;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa + col), a1 = *reinterpret_cast<const f32x4*>(pa + col + 4);
 #pragma unroll
@@ -652,7 +653,8 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
                                          int lane, const f32x4 (&acc)[NI][4], EpiPre<KIND, LNM, NP>& pre, f32x2* lstat = nullptr,
                                          f32x2* lrow = nullptr, const char* fold_vec = nullptr) {
     constexpr bool LOADS = KIND == EPI_RESID || KIND == EPI_GELUGRAD;
-    constexpr bool LN_IN = (LNM & 1) != 0, LN_OUT = (LNM & 2) != 0;
+    constexpr bool LN_IN = (LNM & 1) != 0, LN_OUT = (LNM & 2) != 0, SCALE = (LNM & 4) != 0;
+    constexpr bool FOLDK = LN_IN && KIND != EPI_RESID && KIND != EPI_GELUGRAD;
     constexpr bool FOLD_VEC_LDS = LN_IN && KIND == EPI_GELU_AUX;
     const int rl = lane >> 3;
     float cs[8];
@@ -660,7 +662,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
     for (int j = 0; j < 8; j++) cs[j] = 0.f;
     // row r of the wave's 128 keeps its (mean, rstd) at lrow[r * RS]: a strip of its own (residual kinds), or -- fold kinds -- in
     // place over the first partial of the row in the DMA image (a lane overwrites only the two rows it has read itself)
-    constexpr int RS = (LN_IN && KIND != EPI_RESID) ? NP : 1;
+    constexpr int RS = FOLDK ? NP : 1;
     if constexpr (LN_IN) {
         // (mean, rstd) of the wave's 128 rows, once per item: lane l merges the partials of rows l and l + 64 (epi_prefetch) and
         // parks the pair in LDS; every chunk then takes its row's pair with one ds_read_b64.
@@ -714,7 +716,7 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
             ln_mu = st[0];
             ln_rs = st[1];
         }
-        if (LN_IN && KIND != EPI_RESID) {
+        if (FOLDK) {
             // rstd * acc - rstd*mean * colsum(gamma o W) + (beta.W + b)
             const float mrs = ln_mu * ln_rs;
             if constexpr (FOLD_VEC_LDS) {
@@ -755,13 +757,26 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         } else if (KIND == EPI_GELUGRAD) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] *= gelu_grad_f<false>((float)pre.opnd[c][j]);
+            if constexpr (SCALE) {
+                // the bias gradient wants the column sums of the product itself; what is STORED is rstd o product: the B operand of the
+                // weight gradient on the raw LayerNorm input rows and the A operand of the dgrad that then yields rstd o dn
+                if (ep.colsum) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) cs[j] += v[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] *= ln_rs;
+            }
         } else if (KIND == EPI_RESID) {
             if (ep.drop.thr) {
                 const uint32_t rh = drop_row_hash(ep.drop, (uint32_t)row);
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = apply_drop_rc(ep.drop, rh, (uint32_t)(col + j), v[j]);
             }
-            if constexpr (LN_IN) {
+            if constexpr (SCALE) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = fmaf(ln_rs, (float)pre.opnd[c][j], v[j]);
+            } else if constexpr (LN_IN) {
                 // the residual operand is LayerNorm(raw row), rounded to bf16 like the stored tensor it replaces
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] += (float)(bf16_t)(((float)pre.opnd[c][j] - ln_mu) * ln_rs * pre.lnA[j] + pre.lnB[j]);
@@ -787,13 +802,13 @@ __device__ __forceinline__ void epi_tile(const Epilogue& ep, bf16_t* __restrict_
         // Residual-stream rows of the fused block path are read next by a GEMM (the fold), not streamed by a LayerNorm kernel:
         // default-policy stores there (inference forward of C2 7.88 -> 7.67 ms same-box; non-temporal everywhere else)
 #ifndef EPI_LNOUT_NT_STORE
-        if ((LNM != 0 || XC_PLAIN_RESID) && KIND == EPI_RESID) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
+        if (((LNM != 0 && !SCALE) || XC_PLAIN_RESID) && KIND == EPI_RESID) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
         else if (XC_PLAIN_PLAINKIND && KIND == EPI_PLAIN && LNM == 0) *reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col) = o;
         else
 #endif
 
         __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + (int64_t)row * ldc + col));
-        if (ep.colsum) {
+        if (ep.colsum && !(SCALE && KIND == EPI_GELUGRAD)) {
 #pragma unroll
             for (int j = 0; j < 8; j++) cs[j] += (float)o[j];
         }
@@ -1194,7 +1209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
     // rows the NEXT GEMM folds a LayerNorm into: their A stream is non-temporal (aux = 2) and their output stores default-policy,
     // so the consumer finds its A operand in the Infinity Cache instead of HBM (a fold GEMM on a cold A: +30...+100 us per launch
     // at C2, tools/chain_bench.py; inference forward of C2 7.51 -> 7.22 ms same-box with both, profiles/r5_01_ln_fused.txt).
-    constexpr int A_AUX = (EPI == EPI_RESID && LNM != 0) ? 2 : 0;     // (either c_proj kind alone measured worse than both: r5_01)
+    constexpr int A_AUX = (EPI == EPI_RESID && LNM != 0 && !(LNM & 4)) ? 2 : 0;     // (either c_proj kind alone measured worse than both: r5_01)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -1317,7 +1332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
         // next item's first k-slab goes to stage 0 while this item's epilogue runs out of stage 1
         const int cm0 = m0, cn0 = n0;
         // ... but what a fold epilogue reads from memory is requested FIRST (see fold_dma): in front of the slab, not behind it
-        constexpr bool FOLD = SWAP && (LNM & 1) != 0 && EPI != EPI_RESID && EPI != EPI_GENERIC;
+        constexpr bool FOLD = SWAP && (LNM & 1) != 0 && EPI != EPI_RESID && EPI != EPI_GELUGRAD && EPI != EPI_GENERIC;
         const uint32_t fold_off = 2 * H_IMG + 8 * (16 * 68 * 4) + wave * FOLD_IMG_BYTES(NP);      // behind the waves' staging areas
         if constexpr (FOLD) {
             static_assert(8 * (16 * 68 * 4) + 8 * FOLD_IMG_BYTES(NP) <= 2 * H_IMG, "fold images must fit stage 1");
@@ -2036,6 +2051,17 @@ extern "C" int cmp_gemm_ln_next(const float* in_part, int np, float eps, const f
     t_ln_next = LnEpi{in_part, np, eps, cs, gamma, beta, out_part};
     return CMP_OK;
 }
+// ... and its scale form (round 6: the dgrad epilogues of the fused block path's backward pass): in_part / np / eps as above; with
+// act = 2: C = rstd o (acc * gelu'(aux)) (the column sums armed by cmp_gemm_colsum_next stay those of the unscaled product); with a
+// residual operand: C = acc + rstd o resid
+extern "C" int cmp_gemm_ln_scale_next(const float* in_part, int np, float eps) {
+    t_ln_next = LnEpi{};
+    t_ln_next.in_part = in_part;
+    t_ln_next.np = np;
+    t_ln_next.eps = eps;
+    t_ln_next.scale = 1;
+    return CMP_OK;
+}
 static thread_local float* t_slab_ws = nullptr;       // split-K workspace for this thread's cmp_k_gemm calls
 static thread_local size_t t_slab_bytes = 0;
 extern "C" int cmp_gemm_set_workspace(void* ws, int64_t bytes) {
@@ -2070,6 +2096,8 @@ static bool launch_256(hipStream_t s, int grid, bool swap, int M, int N, int K, 
             if (ep.out_fp32 && lnm == 1) LN_NP(EPI_PLAIN32, 1);
             if (kind == EPI_PLAIN && lnm == 1) LN_NP(EPI_PLAIN, 1);
             if (kind == EPI_GELU_AUX && lnm == 1) LN_NP(EPI_GELU_AUX, 1);
+            if (kind == EPI_GELUGRAD && lnm == 1 && ep.ln.scale) LN_NP(EPI_GELUGRAD, 5);
+            if (kind == EPI_RESID && lnm == 1 && ep.ln.scale) LN_NP(EPI_RESID, 5);
             if (kind == EPI_RESID && lnm == 3) LN_NP(EPI_RESID, 3);
             if (kind == EPI_RESID && lnm == 2) LN_GO(EPI_RESID, 2, 1);
 #undef LN_NP
@@ -2542,6 +2570,10 @@ int gemm_run(void* stream, int dtype, int ta, int tb, int M, int N, int K, const
                 // ln_f into the tied-logits GEMM: fp32 output, the last tile column may be ragged (EPI_PLAIN32)
                 ln_done = !ta && tb && swap && act == 0 && !resid && !ep.drop.thr && M % 256 == 0 && nsplit == 1 && !colsum_out && bias && ex.ln.cs &&
                           (ex.ln.np == 2 || ex.ln.np == 3) && K == 256 * ex.ln.np;
+            } else if (lnm == 1 && ex.ln.scale) {
+                // the backward pass's scale kinds: rows of 256 * np columns own the statistics, whatever N and K are
+                const int kind = (!ta && tb) ? epi_kind_of(ep, M, N, swap, false) : EPI_GENERIC;
+                ln_done = (ex.ln.np == 2 || ex.ln.np == 3) && nsplit == 1 && (kind == EPI_GELUGRAD || (kind == EPI_RESID && !colsum_out));
             } else if (lnm) {
                 const int kind = (!ta && tb) ? epi_kind_of(ep, M, N, swap, false) : EPI_GENERIC;
                 const bool in_ok = !(lnm & 1) || (ex.ln.np >= 2 && ex.ln.np <= 3 && (kind == EPI_RESID ? (ex.ln.gamma && ex.ln.beta && N == 256 * ex.ln.np)

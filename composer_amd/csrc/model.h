@@ -112,6 +112,7 @@ struct cmp_model {
     // ([L] x {c_attn: cs[3E], bias'[3E]; c_fc: cs[4E], bias'[4E]}); refreshed with the transposed copies when a parameter moved.
     void* wdesc_plain = nullptr;       // the 2L matrices that stay unscaled in that mode (both c_proj)
     void* fdesc = nullptr;             // 2L FoldDesc
+    void* ln_sites = nullptr;          // 2L {partials, mean, rstd} pointer triples of the blocks' LayerNorm sites (ln_stats_merge_kernel); rebuilt with the workspace
     float* lnfold = nullptr;
     int64_t fold_stride = 0;           // floats per block in lnfold; c_attn vectors at 0, c_fc vectors at 6E
     int st_state = 0;                  // what ST holds: 0 nothing, 1 plain transposes, 2 the fused path's set
@@ -216,11 +217,18 @@ struct LnBwdFused {     // layernorm_bwd_kernel<.., FUSED>: statistics from part
     float eps = 0.f;
     const float* beta = nullptr;
     void* yout = nullptr;          // xhat * gamma + beta (null: not wanted)
+    int prescaled = 0;             // dy holds rstd o (the gradient): what a dgrad GEMM yields when its A operand was stored rstd-scaled
+                                   // (round 6: the weight gradients of the fused block path run on the raw LayerNorm input rows)
 };
+// G[k, j] = gamma[k] * (G[k, j] - mean_k' G[k', j]) + beta[k] * colsum[j] over one or two [rows, cols] weight gradients that were
+// accumulated as (raw rows)^T . (rstd o D): turns them into LN(raw rows)^T . D (elementwise.hip: wgrad_ln_fix_kernel)
+int wgrad_ln_fix_run(void* stream, float* G0, int rows0, int cols0, const float* gamma0, const float* beta0, const float* colsum0,
+                     float* G1, int rows1, int cols1, const float* gamma1, const float* beta1, const float* colsum1);
 int layernorm_bwd_run(void* stream, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* resid, void* dx, float* dgamma, float* dbeta, void* ws, int rows, int E, int dtype, void* dmask,
                       float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream, bool deterministic, const LnBwdFused* fz = nullptr,
-                      bool keep_dmask = false);
+                      bool keep_dmask = false, bool prescaled = false);
+int ln_stats_merge_run(void* stream, const void* sites_dev, int nsites, int np, float eps, int rows);      // sites: {part, mean, rstd} triples of pointers
 int embed_fwd_stats_run(void* stream, const int32_t* ids, const float* wte, const float* wpe, void* out, float* part, int B, int T,
                         int E, int pos0, float p_drop, uint64_t seed, uint32_t rng_stream);
 int ln_fold_prep_run(void* stream, const float* P, void* ST, float* fold, const void* desc_dev, int ndesc, int max_cols);

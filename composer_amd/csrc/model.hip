@@ -595,6 +595,17 @@ static int ensure_workspace_fill(cmp_model* m, int B, int T) {
         }
     }
     if (ln && m->ST && E % 256 == 0) CHECK_RC(dev_alloc(m, &m->lnf_part, (size_t)M * (E / 256) * 8));
+    if (ln && m->ST && E % 256 == 0) {
+        // the 2L LayerNorm sites of the blocks as {partials, mean, rstd}: merged in one launch by the backward pass of the fused path
+        std::vector<const void*> st;
+        for (int i = 0; i < L; i++) {
+            const LayerAct& a = m->act[i];
+            st.insert(st.end(), {a.ln1_part, a.ln1_mean, a.ln1_rstd, a.ln2_part, a.ln2_mean, a.ln2_rstd});
+        }
+        CHECK_RC(dev_alloc(m, &m->ln_sites, st.size() * sizeof(void*)));
+        HIP_CHECK(hipMemcpyAsync(m->ln_sites, st.data(), st.size() * sizeof(void*), hipMemcpyHostToDevice, m->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
     CHECK_RC(dev_alloc(m, &m->hf, (size_t)M * E * es));
     CHECK_RC(dev_alloc(m, &m->logits, (size_t)M * m->ldz * 4));
     CHECK_RC(dev_alloc(m, &m->dlogits, (size_t)M * m->ldz * es));
@@ -701,7 +712,7 @@ static int refresh_transposed_weights(cmp_model* m, bool fold) {
 // one a LayerNorm kernel has just written), so training passes take it only when COMPOSER_LN_FUSED=2 asks for it (tests).
 static bool ln_fused_ok(const cmp_model* m, int M, int past_len, bool training) {
     if (m->ln_fused_mode == 0) return false;
-    if (training && m->ln_fused_mode != 2) return false;
+    if (training && m->ln_fused_mode != 2 && m->ln_fused_mode != 3) return false;
     if (!m->cfg.use_layer_norm || m->dtype != CMP_BF16 || m->slab || past_len) return false;
     if (m->Ea != m->E || m->E % 256 || m->E < 512 || m->E > 768 || !m->act[0].ln1_part) return false;   // 2 or 3 segments (the fold images' LDS)
     if (M % 256 || (int64_t)(M / 256) * (m->E / 256) < 192) return false;      // gemm_run's `big`: the N = E GEMMs too
@@ -722,10 +733,10 @@ static int colsum_any(cmp_model* m, const void* X, int ldx, float* out, int rows
 }
 static int ln_bwd(cmp_model* m, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                   const void* resid, void* dx, float* dgamma, float* dbeta, int rows, void* dmask, float* colsum, float p_drop,
-                  uint32_t rng_stream, const LnBwdFused* fz = nullptr) {
+                  uint32_t rng_stream, const LnBwdFused* fz = nullptr, bool prescaled = false) {
     // (fused block path: every masked copy is written, dropout or not -- dx does not live until the weight gradients there)
     return layernorm_bwd_run(m->ctx->stream, dy, x, gamma, mean, rstd, resid, dx, dgamma, dbeta, m->ln_ws, rows, m->E, m->dtype,
-                             dmask, colsum, p_drop, m->drop_seed(), rng_stream, m->slab != nullptr, fz, m->fused_last);
+                             dmask, colsum, p_drop, m->drop_seed(), rng_stream, m->slab != nullptr, fz, m->fused_last, prescaled);
 }
 
 #define GEMM_REV (1 << 20)      // gemm() flag (model.hip only): GemmExtra::rev
@@ -973,6 +984,16 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
     // the block's weight-gradient launch reads them, so that launch moves behind ln_1's backward; by then ln_1's backward has
     // produced the NEXT block's MLP masked gradient, hence two alternating buffers for it.
     const bool fused = m->fused_last;
+    // Round 6 (COMPOSER_LN_FUSED=3): the weight gradients of c_fc / c_attn run on the RAW LayerNorm input rows (r / x) --
+    //   n^T . D = gamma o (r^T . D' - 1 (x) (mean^T . D')) + beta (x) colsum(D),   D' = rstd o D,   mean^T . D' = column means of r^T . D'
+    // -- so the backward pass writes no LayerNorm output either: the GELU' dgrad epilogue stores D' = rstd o dfc,
+    // the attention backward kernels store rstd o [dQ | dK | dV], the dgrads that consume them yield rstd o dn / rstd o du (the residual
+    // term of du gets its rstd in the epilogue), which the LayerNorm backward kernels take as they are (LnBwdFused::prescaled), and one
+    // small pass per block applies gamma / beta and the mean term to the two accumulated gradients (wgrad_ln_fix_kernel).
+    const bool raw = fused && m->ln_fused_mode == 3;
+    // (the statistics of all 2L sites, merged from their partials in one launch: the plain LayerNorm backward kernel and the attention
+    //  backward kernels read per-row arrays; the statistics-from-partials form of the LayerNorm backward runs one wave per SIMD less)
+    if (raw) CHECK_RC(ln_stats_merge_run(s, m->ln_sites, 2 * m->L, E / 256, m->cfg.ln_eps, M));
     void* const dmk[2] = {m->dmask, m->dmask3};
     int cur = 0;
     if (allreduce) CHECK_RC(bucket_ready(m, m->L, m->off_lnf_g, m->total, lr, update));
@@ -1004,8 +1025,11 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         };
         if (!group_now) CHECK_RC(wgrad(4 * E, E, a.g, 4 * E, dmo, E, m->G + o.pr_w));
         if (!dmo_ready) CHECK_RC(colsum_any(m, dmo, E, m->G + o.pr_b, M, E));
+        LnEpi ls;
+        ls.np = E / 256; ls.eps = m->cfg.ln_eps; ls.scale = 1;
+        ls.in_part = a.ln2_part;
         CHECK_RC(gemm(m, 0, 1, M, 4 * E, E, dmo, E, m->w(o.pr_w), E, m->dfc, 4 * E, nullptr, 2, a.fc, 4 * E, nullptr, 0, 0, 1,
-                      0.f, 0, 0, m->G + o.fc_b));      // dfc = (dmo.Wpr^T) * gelu'(fc); b_fc grad = column sums of dfc
+                      0.f, 0, 0, m->G + o.fc_b, raw ? &ls : nullptr));      // dfc = (dmo.Wpr^T) * gelu'(fc) [raw: rstd_2 o that]; b_fc grad = column sums of dfc
         if (!group_now) CHECK_RC(wgrad(E, 4 * E, a.n, E, m->dfc, 4 * E, m->G + o.fc_w));
         void* const dao_mask = group_now ? m->dmask2 : m->dmask;
         if (ln) {
@@ -1013,7 +1037,7 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
                           0, 0, 1, 0.f, 0));                                       // dn
             fz.part = a.ln2_part; fz.beta = m->P + o.ln2_b; fz.yout = a.n;
             CHECK_RC(ln_bwd(m, m->tmpE, a.r, m->P + o.ln2_g, a.ln2_mean, a.ln2_rstd, m->dx, m->dr, m->G + o.ln2_g, m->G + o.ln2_b, M,
-                            dao_mask, m->G + o.proj_b, pr, drop_stream(step, i, 2), fused ? &fz : nullptr));   // dr = dx + LN2'(dn); dao, b_proj grad
+                            dao_mask, m->G + o.proj_b, pr, drop_stream(step, i, 2), (fused && !raw) ? &fz : nullptr, raw));   // dr = dx + LN2'(dn); dao, b_proj grad
         } else {
             CHECK_RC(gemm(m, 0, 1, M, E, 4 * E, m->dfc, 4 * E, m->w(o.fc_w), 4 * E, m->dr, E, nullptr, 0, nullptr, 0, m->dx, E,
                           0, 1, 0.f, 0));                                          // dr = dx + dn
@@ -1031,15 +1055,17 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
         CHECK_RC(gemm(m, 0, 1, M, Ea, E, dao, E, m->w(o.proj_w), E, m->tmpE, Ea, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0.f,
                       0));                                                         // datt
         const bool det = m->slab != nullptr;     // the fused bias sums are float atomics: a separate fixed-order pass instead
+        AttnLnRows alr;
+        if (raw) alr.rstd = a.ln1_rstd;
         CHECK_RC(attn_bwd_run(s, a.qkv, a.att, m->tmpE, a.lse, m->delta, m->dqkv, B, T, m->H, m->D, attn_scale(m),
-                              dt, pa, m->drop_seed(), drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b));   // b_attn grad = column sums of dqkv
+                              dt, pa, m->drop_seed(), drop_stream(step, i, 1), det ? nullptr : m->G + o.attn_b, alr));   // b_attn grad = column sums of dqkv
         if (det) CHECK_RC(colsum_det(m, m->dqkv, 3 * Ea, m->G + o.attn_b, M, 3 * Ea));
         auto group_launch = [&]() -> int {
             const WgradProblem wp[4] = {
                 {a.g, 4 * E, dmo, E, m->G + o.pr_w, E, 4 * E, E},                  // dWpr   = g^T . dmo
-                {a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, E, 4 * E},           // dWfc   = n^T . dfc
+                {raw ? a.r : a.n, E, m->dfc, 4 * E, m->G + o.fc_w, 4 * E, E, 4 * E},           // dWfc   = n^T . dfc        [raw: r^T . (rstd_2 o dfc)]
                 {a.att, Ea, dao, E, m->G + o.proj_w, E, Ea, E},                    // dWproj = att^T . dao
-                {a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w, 3 * Ea, E, 3 * Ea}};    // dWattn = u^T . dqkv
+                {raw ? m->xs[i] : a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w, 3 * Ea, E, 3 * Ea}};    // dWattn = u^T . dqkv  [raw: x^T . (rstd_1 o dqkv)]
             GemmExtra ex;
             ex.role = 2;
             ex.max_wgs = m->ctx->dp_on() ? m->ctx->gemm_max_wgs : 0;
@@ -1050,28 +1076,33 @@ static int backward(cmp_model* m, const int32_t* x_dev, int B, int T, int64_t st
             CHECK_RC(wgrad_group_run(s, &m->wgrad_groups[i], wp, 4, M, ex, &handled));
             if (!handled) {          // shapes outside the grouped kernel's domain (M % 32, ...): one launch each, as without grouping
                 CHECK_RC(wgrad(4 * E, E, a.g, 4 * E, dmo, E, m->G + o.pr_w));
-                CHECK_RC(wgrad(E, 4 * E, a.n, E, m->dfc, 4 * E, m->G + o.fc_w));
+                CHECK_RC(wgrad(E, 4 * E, wp[1].A, E, m->dfc, 4 * E, m->G + o.fc_w));
                 CHECK_RC(wgrad(Ea, E, a.att, Ea, dao, E, m->G + o.proj_w));
-                CHECK_RC(wgrad(E, 3 * Ea, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w));
+                CHECK_RC(wgrad(E, 3 * Ea, wp[3].A, E, m->dqkv, 3 * Ea, m->G + o.attn_w));
+            }
+            if (raw) {               // gamma / beta and the mean term on the two gradients that were accumulated on raw rows
+                CHECK_RC(wgrad_ln_fix_run(s, m->G + o.fc_w, E, 4 * E, m->P + o.ln2_g, m->P + o.ln2_b, m->G + o.fc_b,
+                                          m->G + o.attn_w, E, 3 * E, m->P + o.ln1_g, m->P + o.ln1_b, m->G + o.attn_b));
             }
             return CMP_OK;
         };
-        if (group_now && !fused) {
+        if (group_now && (!fused || raw)) {
             CHECK_RC(group_launch());
         } else if (!group_now) {
             CHECK_RC(wgrad(E, 3 * Ea, a.u, E, m->dqkv, 3 * Ea, m->G + o.attn_w));
         }
         if (ln) {
+            ls.in_part = a.ln1_part;
             CHECK_RC(gemm(m, 0, 1, M, E, 3 * Ea, m->dqkv, 3 * Ea, m->w(o.attn_w), 3 * Ea, m->tmpE, E, nullptr, 0, nullptr, 0, m->dr,
-                          E, 0, 1, 0.f, 0));                                       // du = dr + dqkv.Wattn^T
+                          E, 0, 1, 0.f, 0, 0, nullptr, raw ? &ls : nullptr));      // du = dr + dqkv.Wattn^T  [raw: rstd_1 o du]
             // dx_in = LN1'(du): no skip connection around LN1; feeds layer i-1's MLP branch (or the embedding for i = 0)
             fz.part = a.ln1_part; fz.beta = m->P + o.ln1_b; fz.yout = a.u;
             void* const next_mask = fused ? dmk[cur ^ 1] : m->dmask;
             CHECK_RC(ln_bwd(m, m->tmpE, m->xs[i], m->P + o.ln1_g, a.ln1_mean, a.ln1_rstd, nullptr, m->dx, m->G + o.ln1_g,
                             m->G + o.ln1_b, M, i > 0 ? next_mask : nullptr, i > 0 ? m->G + m->lo[i - 1].pr_b : nullptr, pr,
-                            drop_stream(step, i > 0 ? i - 1 : 0, 3), fused ? &fz : nullptr));
+                            drop_stream(step, i > 0 ? i - 1 : 0, 3), (fused && !raw) ? &fz : nullptr, raw));
             if (fused) {
-                CHECK_RC(group_launch());          // g^T.dmo, n^T.dfc, att^T.dao, u^T.dqkv -- u and n as just written
+                if (!raw) CHECK_RC(group_launch());          // g^T.dmo, n^T.dfc, att^T.dao, u^T.dqkv -- u and n as just written
                 cur ^= 1;
             }
             dmo_ready = true;

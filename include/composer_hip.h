@@ -302,6 +302,24 @@ int cmp_k_ln_fold_prep(void* stream, const float* W, const float* bias, const fl
                        float* cs, float* bias_out, int E, int N);
 int cmp_gemm_ln_next(const float* in_part, int np, float eps, const float* cs, const float* gamma, const float* beta,
                      float* out_part);
+/* Round 6, the backward pass of the LayerNorm-fused block path (weight gradients on the RAW LayerNorm input rows, no LayerNorm output
+ * ever written).  One-shot arming calls like cmp_gemm_ln_next, consumed by this thread's next cmp_k_gemm / cmp_k_attn_bwd:
+ *   cmp_gemm_ln_scale_next: the rows' rstd (merged from in_part) is a FACTOR -- with act = 2 (gelu' epilogue) the launch stores
+ *     C = rstd o (acc * gelu'(aux)) and still sends the column sums of the UNSCALED product to cmp_gemm_colsum_next's vector; with
+ *     a residual operand it stores C = acc + rstd o resid.
+ *   cmp_k_ln_stats_merge: (mean, rstd) per row from the rows' partial statistics [rows][np][2] (the model merges all its sites in one launch).
+ *   cmp_attn_bwd_ln_next: cmp_k_attn_bwd stores rstd[token] o [dQ | dK | dV].
+ *   cmp_k_layernorm_bwd_prescaled: the LayerNorm backward (mean / rstd arrays) on a dy that holds rstd o (the gradient).
+ *   cmp_k_wgrad_ln_fix: G[k, j] = gamma[k] * (G[k, j] - mean over k' of G[k', j]) + beta[k] * colsum[j] -- turns R = (raw rows)^T .
+ *     (rstd o D) into LN(raw rows)^T . D: the mean term mean^T . (rstd o D) IS the column mean of R, a row's mean being the mean of
+ *     that row as stored. */
+int cmp_gemm_ln_scale_next(const float* in_part, int np, float eps);
+int cmp_k_ln_stats_merge(void* stream, const float* part, int np, float eps, float* mean, float* rstd, int rows);
+int cmp_attn_bwd_ln_next(const float* rstd);
+int cmp_k_layernorm_bwd_prescaled(void* stream, const void* dy_scaled, const void* x, const float* gamma, const float* mean,
+                                  const float* rstd, const void* resid, void* dx, float* dgamma, float* dbeta, void* ws,
+                                  int rows, int E, void* dmask, float* colsum, float p_drop, uint64_t seed, uint32_t rng_stream);
+int cmp_k_wgrad_ln_fix(void* stream, float* G, int rows, int cols, const float* gamma, const float* beta, const float* colsum);
 int cmp_k_layernorm_bwd_parts(void* stream, const void* dy, const void* x, const float* gamma, const float* beta,
                               const float* part, float eps, const void* resid, void* dx, void* yout, float* dgamma,
                               float* dbeta, void* ws, int rows, int E, void* dmask, float* colsum, float p_drop,

@@ -251,6 +251,136 @@ def test_layernorm_backward_from_partials_writes_the_forward_output(lib, E, p):
     assert rel(csum.cpu().numpy(), dmask.double().cpu().numpy().sum(0)) < 1e-4
 
 
+# --------------------------------------------------------------------------------------------- round 6: the backward pass without u / n
+def _gelu_grad64(x):
+    c, k = np.sqrt(2 / np.pi), 0.044715
+    t = np.tanh(c * (x + k * x ** 3))
+    return 0.5 * (1 + t) + 0.5 * x * (1 - t * t) * c * (1 + 3 * k * x * x)
+
+
+@pytest.mark.parametrize("E", [512, 768])
+def test_scale_epilogues_carry_the_rows_rstd_as_a_factor(lib, E):
+    """The two dgrad epilogues of the raw-row backward pass (gemm.hip: LNM bit 2).  GELU' kind: C = rstd o (A.W^T * gelu'(aux)) with
+    rstd merged from the LayerNorm input rows' partials, while the armed column sums stay those of the UNSCALED product (the c_fc
+    bias gradient).  Residual kind: C = A.W^T + rstd o resid (du with its dr term)."""
+    M, K, N = 768, 512, 1024
+    rng = np.random.default_rng(E)
+    A = bf(rng.normal(0, 1.0, (M, K)))
+    W = bf(rng.normal(0, 0.05, (N, K)))
+    aux = bf(rng.normal(0, 1.5, (M, N)))
+    rows = bf(rng.normal(1.5, 2.0, (M, E)))                          # the LayerNorm input rows the statistics belong to
+    r64 = rows.double().cpu().numpy()
+    part = f32(parts_of(r64))
+    rs = 1 / np.sqrt(r64.var(-1, keepdims=True) + EPS)
+    acc = A.double().cpu().numpy() @ W.double().cpu().numpy().T
+    # GELU' kind
+    csum = torch.zeros(N, device="cuda")
+    Cm = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ck(lib, lib.cmp_gemm_colsum_next(P(csum)))
+    ck(lib, lib.cmp_gemm_ln_scale_next(P(part), E // 256, EPS))
+    ck(lib, lib.cmp_k_gemm(stream(), BF16, 0, 1, M, N, K, P(A), K, P(W), K, P(Cm), N, None, 2, P(aux), N, None, 0, 0, 1, 0.0, 0, 0, 8))
+    torch.cuda.synchronize()
+    prod = acc * _gelu_grad64(aux.double().cpu().numpy())
+    assert rel(Cm.double().cpu().numpy(), rs * prod) < 8e-3
+    assert rel(csum.cpu().numpy(), prod.sum(0)) < 2e-4
+    # residual kind
+    res = bf(rng.normal(0, 1.0, (M, N)))
+    Cm2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ck(lib, lib.cmp_gemm_ln_scale_next(P(part), E // 256, EPS))
+    ck(lib, lib.cmp_k_gemm(stream(), BF16, 0, 1, M, N, K, P(A), K, P(W), K, P(Cm2), N, None, 0, None, 0, P(res), N, 0, 1, 0.0, 0, 0, 8))
+    torch.cuda.synchronize()
+    assert rel(Cm2.double().cpu().numpy(), acc + rs * res.double().cpu().numpy()) < 8e-3
+
+
+@pytest.mark.parametrize("E", [512, 768])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_layernorm_backward_takes_a_prescaled_gradient(lib, E, p):
+    """The prescaled form of the LayerNorm backward (statistics merged from the partials first): dy holds rstd o gradient (what a dgrad yields when its A operand was stored rstd-scaled); dx, the masked
+    copy, its column sums and both parameter gradients are those of the plain form on the true gradient."""
+    rows = 1300
+    rng = np.random.default_rng(E + int(10 * p) + 1)
+    x = bf(rng.normal(1.0, 2.0, (rows, E)))
+    x64 = x.double().cpu().numpy()
+    mu, var = x64.mean(-1, keepdims=True), x64.var(-1, keepdims=True)
+    rs = 1 / np.sqrt(var + EPS)
+    dy_true = rng.normal(0, 1.0, (rows, E))
+    dys = bf(rs * dy_true)                                           # the stored, scaled gradient
+    dy64 = dys.double().cpu().numpy() / rs                           # ... and the gradient it stands for
+    res = bf(rng.normal(0, 1.0, (rows, E)))
+    g = (1 + 0.3 * rng.normal(size=E)).astype(np.float32)
+    be = rng.normal(0, 0.2, E).astype(np.float32)
+    part = f32(parts_of(x64))
+    mean_d, rstd_d = torch.zeros(rows, device="cuda"), torch.zeros(rows, device="cuda")
+    ck(lib, lib.cmp_k_ln_stats_merge(stream(), P(part), E // 256, EPS, P(mean_d), P(rstd_d), rows))      # what the backward pass does for all sites at once
+    torch.cuda.synchronize()
+    assert np.abs(mean_d.cpu().numpy() - mu[:, 0]).max() < 1e-5 and rel(rstd_d.cpu().numpy(), rs[:, 0]) < 1e-5
+    ws = torch.zeros(lib.cmp_k_layernorm_bwd_ws(rows, E) // 4, device="cuda")
+    dx, dmask = (torch.zeros(rows, E, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    dg, db, csum = torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    ck(lib, lib.cmp_k_layernorm_bwd_prescaled(stream(), P(dys), P(x), P(f32(g)), P(mean_d), P(rstd_d), P(res), P(dx), P(dg), P(db),
+                                              P(ws), rows, E, P(dmask), P(csum), p, 5, 2))
+    torch.cuda.synchronize()
+    g64 = g.astype(np.float64)
+    xh = (x64 - mu) * rs
+    gg = dy64 * g64
+    want_dx = res.double().cpu().numpy() + rs * (gg - gg.mean(-1, keepdims=True) - xh * (gg * xh).mean(-1, keepdims=True))
+    assert rel(dx.double().cpu().numpy(), want_dx) < 6e-3
+    assert rel(dg.cpu().numpy(), (dy64 * xh).sum(0)) < 2e-4
+    assert rel(db.cpu().numpy(), dy64.sum(0)) < 2e-4
+    keep = O.dropout_keep_rows(5, 2, rows, E, p) if p > 0 else np.ones((rows, E), bool)
+    assert rel(dmask.double().cpu().numpy(), np.where(keep, dx.double().cpu().numpy() / (1 - p), 0.0)) < 5e-3
+
+
+@pytest.mark.parametrize("D,H", [(64, 8), (32, 16), (128, 4)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_backward_scales_its_rows_by_the_layernorm_rstd(lib, D, H, p):
+    """AttnLnRows: [dQ | dK | dV] rows stored times the rstd of their token's LayerNorm statistics, the c_attn bias gradient (column sums
+    of the UNSCALED gradient) untouched -- against the plain launch on the same inputs."""
+    B, T = 3, 384
+    E = H * D
+    rng = np.random.default_rng(D + int(10 * p))
+    qkv = bf(rng.normal(0, 1.0, (B * T, 3 * E)))
+    d_o = bf(rng.normal(0, 1.0, (B * T, E)))
+    o = torch.zeros(B * T, E, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * T, device="cuda")
+    ck(lib, lib.cmp_k_attn_fwd(stream(), P(qkv), P(o), P(lse), B, T, H, D, 1, BF16, p, 3, 7))
+    rs = rng.uniform(0.3, 3.0, (B * T, 1))
+    rs_d = f32(rs[:, 0])
+    outs = []
+    for scaled in (False, True):
+        dqkv = torch.zeros(B * T, 3 * E, dtype=torch.bfloat16, device="cuda")
+        delta = torch.zeros(B * H * T, device="cuda")
+        bias = torch.zeros(3 * E, device="cuda")
+        ck(lib, lib.cmp_attn_bwd_bias_next(P(bias)))
+        if scaled:
+            ck(lib, lib.cmp_attn_bwd_ln_next(P(rs_d)))
+        ck(lib, lib.cmp_k_attn_bwd(stream(), P(qkv), P(o), P(d_o), P(lse), P(delta), P(dqkv), B, T, H, D, 1, BF16, p, 3, 7))
+        torch.cuda.synchronize()
+        outs.append((dqkv.double().cpu().numpy(), bias.cpu().numpy().astype(np.float64)))
+    (plain, bplain), (sc, bsc) = outs
+    assert rel(sc, rs * plain) < 1.2e-2                              # (two bf16 roundings apart)
+    assert rel(bsc, bplain) < 1e-3                                   # float atomics: not bitwise
+
+
+def test_weight_gradient_on_raw_rows_becomes_the_one_on_layernorm_rows(lib):
+    """wgrad_ln_fix_kernel: R = r^T . (rstd o D) accumulated on the RAW rows turns into LN(r)^T . D with nothing but R, gamma, beta and
+    colsum(D): the mean term mean^T . (rstd o D) is the column mean of R, because a row's mean is the mean of that row as stored."""
+    rows, E, N = 4096, 512, 768
+    rng = np.random.default_rng(4)
+    r64 = bf(rng.normal(0.7, 1.3, (rows, E))).double().cpu().numpy()
+    Dm = rng.normal(0, 1.0, (rows, N))
+    g = (1 + 0.3 * rng.normal(size=E)).astype(np.float32)
+    be = rng.normal(0, 0.2, E).astype(np.float32)
+    mu, var = r64.mean(-1, keepdims=True), r64.var(-1, keepdims=True)
+    rs = 1 / np.sqrt(var + EPS)
+    R = r64.T @ (rs * Dm)
+    G = f32(R)
+    ck(lib, lib.cmp_k_wgrad_ln_fix(stream(), P(G), E, N, P(f32(g)), P(f32(be)), P(f32(Dm.sum(0)))))
+    torch.cuda.synchronize()
+    want = ln64(r64, g.astype(np.float64), be.astype(np.float64)).T @ Dm
+    assert rel(G.cpu().numpy(), want) < 2e-5
+
+
 # --------------------------------------------------------------------------------------------- model level
 def _model(E, H, L, T, B, p, seed=3):
     from composer_amd.transformer import Transformer
@@ -265,8 +395,9 @@ def _fused(m):
     return f.value, n.value
 
 
+@pytest.mark.parametrize("form", ["2", "3"])          # 2: the LayerNorm backward kernels write u / n; 3 (round 6): weight gradients on the raw rows
 @pytest.mark.parametrize("E,H,L,T,B,p", [(512, 8, 2, 256, 96, 0.1), (768, 12, 2, 512, 32, 0.0)])
-def test_fused_path_matches_the_unfused_path_and_the_oracle(E, H, L, T, B, p):
+def test_fused_path_matches_the_unfused_path_and_the_oracle(E, H, L, T, B, p, form):
     """Same weights, same batch, same dropout masks: loss and EVERY parameter gradient of the fused path against (a) the unfused
     path of the same library (COMPOSER_LN_FUSED=0) and (b) the bf16-rounding float64 oracle on a slice of the batch small enough
     for it (rows are independent up to the 1/(B*T) loss scale); then three train steps of each path track each other."""
@@ -281,7 +412,7 @@ def test_fused_path_matches_the_unfused_path_and_the_oracle(E, H, L, T, B, p):
     x, y = O.synthetic_batch(rng, V, B, T)
     res = {}
     for mode in ("1", "0"):
-        os.environ["COMPOSER_LN_FUSED"] = "2" if mode == "1" else "0"          # 2: training passes take the fused path too
+        os.environ["COMPOSER_LN_FUSED"] = form if mode == "1" else "0"         # 2 / 3: training passes take the fused path too
         try:
             m = _model(E, H, L, T, B, p)
             m.set_weights(params)
