@@ -1270,7 +1270,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();      // stage 0 of this item has landed (vmcnt(0) rides on the barrier); previous epilogue left stage 1
         if (!run) kt1 = kt0;                        // (nothing of the scheduler inside the k-loop, see ItemPuller)
-        constexpr bool early = false;
         for (int kt = kt0; kt < kt1; kt++) {
             const int st = (kt - kt0) & 1;
             const char* ia = smem + st * 2 * H_IMG;
@@ -1346,7 +1345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(int M, int N, int
             item_coords(next, m0, n0, kt0, kt1);
             ra = make_rsrc(A, A_KM, A_KM ? M : K, lda, m0);
             rb = make_rsrc(B, B_KM, B_KM ? N : K, ldb, n0);
-            if (kt0 < kt1 && !early) {          // (early: that slab went out in front of the last k-step)
+            if (kt0 < kt1) {
                 glds_tile256<A_KM, A_AUX>(ra, smem, lda * 2, kt0 * G_BK, wave, lane);
                 glds_tile256<B_KM>(rb, smem + H_IMG, ldb * 2, kt0 * G_BK, wave, lane);
             }
