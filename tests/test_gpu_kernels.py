@@ -453,6 +453,8 @@ def check_attention_groups(lib, B, H, D, T, dtype, p, groups):
     # no 128-position block of any (batch, head) group left at its zero initialisation: every block was visited by both launches
     # (single positions can be exactly zero: dq of position 0, dv of a position whose probabilities were all dropped)
     for t0 in range(0, T, 128):
+        if p > 0 and T - t0 < 8:
+            continue        # (a last block of a few positions: dk / dv of the final keys are all-zero whenever their few probabilities were dropped)
         assert bool((oh[:, t0:t0 + 128] != 0).any(-1).any(1).all()) and bool((lh[:, :, t0:t0 + 128] != 0).any(-1).all()), t0
         assert bool((gh[:, t0:t0 + 128] != 0).any(-1).any(1).all()), t0
     tol = TOL[dtype] * (3 if dtype == BF16 else 1)
