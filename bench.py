@@ -19,7 +19,7 @@ region), `cpu_baseline` (the CPU restatement of the reference path on the host c
 `decode` (BASELINE config 5, with its own memory roofline) and, at N=1, more driver-timed objects: `classes` (the live
 roofline of EVERY kernel class of the step, three extra steps each; every entry carries `algorithmic_bytes` and, when
 profiles/hbm_traffic.json covers the run, the PMC-measured in-step `traffic`), `b32` (SURVEY's C2 batch, 32 sequences, with its
-own `classes`) and `c4` (BASELINE config 4), each `{ms_per_step, value, model_mfma_frac}` from 3 warm-up + 10 timed steps, and
+own `classes`) and `c4` (BASELINE config 4), each `{ms_per_step, value, model_mfma_frac}` from 5 warm-up + 20 timed steps, and
 `forward` (the north-star quantity: the inference forward pass of C2 and C4 as a fraction of the bf16 MFMA peak).
 Under a launcher (any N, also 1) the line carries `comm`: the gradient exchange's exposed (non-overlapped) time per step, `ranks`
 (every rank's own ms/step and exposed ms, gathered over gloo -- a straggler shows up by rank) and `runtime` (RCCL version and the
@@ -299,8 +299,9 @@ def decode_bench(device):
                                  "launch-boundary bound, not byte bound" % (weight_bytes / 1e6, kv_bytes / 1e6, 5 * L + 2)}}
 
 
-def side_config(name, Bq, device, dropout, steps=10, warmup=3, classes=False):
-    """A short timed run of another configuration on the same GPU (N=1): 3 warm-up + 10 steps, inputs resident in HBM."""
+def side_config(name, Bq, device, dropout, steps=20, warmup=5, classes=False):
+    """A short timed run of another configuration on the same GPU (N=1): 5 warm-up + 20 steps, inputs resident in HBM.  (Round 6: 3 + 10
+    steps read 7.82 ms for C2 at B=32 once where the same process on the same box reads 7.25 on every repeat, tools/b32_probe.py.)"""
     import torch
     from composer_amd.transformer import Transformer
     cf = CONFIGS[name]
