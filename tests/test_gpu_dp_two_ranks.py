@@ -243,4 +243,45 @@ def test_exchange_seam_failure_fails_the_step_and_poisons_the_model():
     assert isinstance(m.exchange_error, RuntimeError)
     with pytest.raises(_lib.HipLibraryError, match="earlier data-parallel step failed"):       # a bucket had already been updated
         m.train_step(x, y, 1e-3)
+    # the flag falls when EVERY tensor has been reloaded, not at the first one (a half-finished reload must not train) ...
+    weights = m.get_weights()
+    names = list(m.parameter_names)
+    m.set_parameter(names[0], weights[names[0]])
+    with pytest.raises(_lib.HipLibraryError, match="earlier data-parallel step failed"):
+        m.train_step(x, y, 1e-3)
+    m.set_weights(weights)
+    seen.clear()
+    seen.extend([0] * 10)                                                # (the flaky link stays up from here on)
+    loss, _ = m.train_step(x, y, 1e-3)
+    assert np.isfinite(loss)
     m.close()
+
+
+def test_inference_after_a_failed_step_sees_the_parameters_as_they_are():
+    """a data-parallel step that fails after some buckets ran Adam never reaches the end-of-step version bump; the transposed /
+    LayerNorm-folded weight copies of the bf16 forward must be rebuilt all the same -- an inference pass right after the failure equals
+    one on a fresh model given the (partially stepped) parameters."""
+    from composer_amd.transformer import Transformer
+    from composer_amd import _lib
+    E, H, L, T, B = 512, 8, 2, 256, 96                                   # large enough for the fused inference path (folded copies)
+    kw = dict(attention_dropout_rate=0.0, residual_dropout_rate=0.0, dtype="bf16", seed=0, max_batch=B, max_seq=T)
+    m = Transformer(390, E, T, L, H, **kw)
+    m.initialize_parameters(3)
+    calls = []
+
+    def flaky(ptr, count, stream):
+        calls.append(count)
+        if len(calls) == 4:
+            raise RuntimeError("link down")
+    m.init_data_parallel_exchange(0, 1, flaky)
+    x, y = O.synthetic_batch(np.random.default_rng(2), 390, B, T)
+    before = np.asarray(m(x, training=False)[0]).copy()                  # (builds the folded copies for the initial parameters)
+    with pytest.raises(_lib.HipLibraryError, match="exchange function failed"):
+        m.train_step(x, y, 1e-2)
+    after = np.asarray(m(x, training=False)[0]).copy()
+    ref = Transformer(390, E, T, L, H, **kw)
+    ref.set_weights(m.get_weights())
+    want = np.asarray(ref(x, training=False)[0]).copy()
+    m.close(); ref.close()
+    assert np.abs(after - before).max() > 1e-3                           # some buckets did step
+    assert np.abs(after - want).max() <= 2e-2 * np.abs(want).max()      # ... and the pass saw them
