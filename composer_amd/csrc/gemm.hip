@@ -1541,10 +1541,7 @@ struct WgProb { const bf16_t* A; const bf16_t* B; float* C; int M, N, lda, ldb, 
 // over K, and the launch keeps 43-46 us of it with no output at all (ramp-up, imbalance); measured on one box (C2 block, 131 072
 // tokens, tools/wgrad_tail_probe.py): no partial traffic 804 us, float atomics 815, this form 837 (slot stores +9, the 48 last
 // arrivers reading 5 slots each at ~52 GB/s +24); whole C2 step 25.70 (atomics) -> 26.16 ms.  profiles/NEGATIVE_RESULTS.md, round 6.
-struct WgLa { float* ws; int* cnt; const int* slot0; };
-#ifndef WGLA_DIAG
-#define WGLA_DIAG 0      // TEMP (measurement): 1 no reduction loads, 2 no partial stores either, 3 plain (not sc1) partial stores
-#endif      // workspace slots of 256 x 256 floats; one counter and first slot per tile
+struct WgLa { float* ws; int* cnt; const int* slot0; };      // workspace slots of 256 x 256 floats; one counter and first slot per tile
 
 // NWM: wave rows (1: 128x256 tile, 4 waves, 2 workgroups per CU; 2: 256x256 tile, 8 waves, 1 per CU).  NST: LDS stages.
 template <bool A_KM, bool B_KM, bool SWAP, int NWM, int NST, bool DIAG, int EPI, bool GROUPED, bool WGLA = false>

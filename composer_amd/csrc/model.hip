@@ -298,7 +298,7 @@ extern "C" int cmp_model_create(cmp_ctx* ctx, const cmp_model_cfg* cfg, cmp_mode
     HIP_CHECK(hipSetDevice(ctx->device));
     cmp_model* m = new cmp_model();
     m->ctx = ctx;
-    {   // COMPOSER_LN_FUSED is read ONCE per model, here (tests switch it between models): 0 off, 2 training passes too
+    {   // COMPOSER_LN_FUSED is read ONCE per model, here (tests switch it between models): 0 off, 2 / 3 training passes too
         const char* e = getenv("COMPOSER_LN_FUSED");
         m->ln_fused_mode = e ? atoi(e) : -1;
     }
@@ -709,7 +709,9 @@ static int refresh_transposed_weights(cmp_model* m, bool fold) {
 // pass (no past, none of cmp_forward_ex's optional inputs).  COMPOSER_LN_FUSED=0 switches it off (A/B timing, tests).
 // Measured (profiles/r5_01_ln_fused.txt): the inference forward of C2 7.87 -> 7.65 ms; a TRAIN step loses 1.5-2 % (the two LayerNorm
 // backward kernels of a block write u / n instead of the forward kernels, and the fold GEMMs read a colder A operand than the
-// one a LayerNorm kernel has just written), so training passes take it only when COMPOSER_LN_FUSED=2 asks for it (tests).
+// one a LayerNorm kernel has just written), so training passes take it only when COMPOSER_LN_FUSED=2 asks for it (tests), or =3: round 6's
+// form of the backward pass (weight gradients on the raw LayerNorm input rows, no u / n written at all) -- measured a tie with the
+// unfused train step (profiles/r6_02_ln_raw_training.txt).
 static bool ln_fused_ok(const cmp_model* m, int M, int past_len, bool training) {
     if (m->ln_fused_mode == 0) return false;
     if (training && m->ln_fused_mode != 2 && m->ln_fused_mode != 3) return false;

@@ -84,3 +84,22 @@ def test_hot_kernels_do_not_spill():
              or re.match(r"void gemm_bf16_fast_kernel<true, true, true, [1-4], true>", p)}
     assert len(small) == 12, sorted(small)
     assert not {p: v for p, v in small.items() if v["spill"] or v["scratch"]}, small
+
+
+def test_shipped_translation_units_hold_shipped_kernels_only():
+    """the measurement ladders (`*_DIAG`), the round-3 attention forwards and the first-generation decode kernels live in
+    composer_amd/csrc/experiments/*_lab.hip (compiled only by tools/ab_build.py -DCOMPOSER_EXPERIMENTS); the sources the product library
+    is built from carry no such branch -- running the strip tool over them again changes nothing -- and the build does not list the lab."""
+    import importlib.util
+    import re as _re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("strip_lab", os.path.join(root, "tools", "strip_lab.py"))
+    sl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sl)
+    from composer_amd import build as B
+    for src in B.SOURCES:
+        text = open(os.path.join(B.CSRC, src)).read()
+        assert not _re.search(r"COMPOSER_EXPERIMENTS|\b[A-Z0-9]+_DIAG\b", text), src
+        assert sl.strip(text) == text, src
+    assert all(os.path.dirname(s) == "" for s in B.SOURCES)                       # nothing under experiments/ is part of the library
+    assert sorted(os.listdir(os.path.join(B.CSRC, "experiments"))) == ["attention_lab.hip", "decode_lab.hip", "gemm_lab.hip"]
