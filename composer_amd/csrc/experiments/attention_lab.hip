@@ -2256,7 +2256,9 @@ extern "C" int cmp_k_attn_bwd(void* stream, const void* qkv, const void* o, cons
 
 int attn_bwd_run(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_ws, void* dqkv,
                  int B, int T, int H, int D, float sc, int dtype, float p_drop, uint64_t seed, uint32_t rng_stream,
-                 float* bias_grad) {
+                 float* bias_grad, AttnLnRows lr) {
+    // (round-6 signature; the lab copy has no rstd-scaled stores: COMPOSER_LN_FUSED=3 needs the product library)
+    CMP_REQUIRE(!lr.rstd, "attention backward (experiments build): LayerNorm row scaling is not in the lab copy");
     if (B * T == 0) return CMP_OK;
     hipStream_t s = (hipStream_t)stream;
     DropCfg d = make_drop(p_drop, seed, rng_stream);

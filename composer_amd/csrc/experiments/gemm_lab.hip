@@ -2182,6 +2182,10 @@ void sched_ws_free(SchedWs* w) {
 // ~800 and four split-K launches take 902-954; at C4's 108 tiles it lost 3.6 % of the step.)
 // Cost model in k-steps of 32 (tools/kbench.py wgradgroup: 0.91 us per k-step, 54 us = 59 k-steps of atomic epilogue per launch):
 // grouped = ceil(nk / s) * rounds + 59 against the sum over problems of nk / split_p + 59 -- the grouped launch is used when it wins.
+// (round-6 entry points the model driver links against; the lab copy keeps the float-atomic grouped launch only)
+void wgrad_ws_free(WgradWs* w) {
+    if (w && w->ptr) { (void)hipFree(w->ptr); w->ptr = nullptr; w->bytes = 0; }
+}
 void wgrad_group_free(WgradGroup* g) {
     if (g && g->dev) { (void)hipFree(g->dev); g->dev = nullptr; g->dev_bytes = 0; g->key.clear(); }
 }
